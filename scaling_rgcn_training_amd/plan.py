@@ -1,0 +1,222 @@
+"""Graph plan: the HBM layout the HIP kernels walk.
+
+Built once per (graph, tile size, direction, node range) from the COO tensors the
+reference hands to the layer (``edge_index[2,E]`` int64, ``edge_type[E]`` int64, unsorted,
+duplicates kept: /root/reference/graphs/graph.py:55-69) and cached, so the public
+``forward(x, edge_index, edge_type)`` signature stays PyG's (SURVEY.md 8b "Ownership").
+PyG recomputes masks and counts on every call; here they are computed once.
+
+Layout (all int32 / float32, device resident):
+
+* output nodes of the owned range ``[node_begin, node_end)`` are cut into TILES of ``tile``
+  consecutive nodes; one workgroup owns a tile's accumulator in LDS;
+* the edges scattering into a tile are grouped by relation; each (tile, relation) group is cut
+  into CHUNKS of ``CHUNK`` = 64 edge slots (the last one padded), so a chunk is
+  relation-homogeneous (one MFMA B operand) and exactly one LDS-DMA ring slot;
+* the self-loop (PyG ``root``) is relation id ``num_relations`` with one pseudo edge per node;
+* per slot: ``slot_src`` (row to gather, -1 = padding), ``slot_w`` (edge weight
+  ``1 / max(1, c[dst, rel])`` for ``aggr='mean'``, 0 = padding), ``slot_dstl`` (row inside the tile);
+* per chunk: ``chunk_rel``, ``chunk_cnt``, ``chunk_tile``; ``tile_ptr`` gives the tile-major
+  chunk ranges (forward / dX kernels) and ``rel_order`` the relation-major order (dW kernel).
+
+The transposed plan (``direction='bwd'``) swaps the roles of source and destination and keeps
+the forward weights, so dX is the same kernel run on it with W_r^T (SURVEY.md 7 "Backward dX
+without atomics").  Everything here is torch tensor plumbing and runs on CPU or GPU alike.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+CHUNK = 64  # edge slots per chunk == rows of one LDS ring slot (must match csrc/rgcn_common.h)
+
+
+@dataclass
+class TilePlan:
+    n_nodes: int          # nodes of the whole graph (rows of the gathered matrix)
+    node_begin: int       # first owned output node (multiple of tile)
+    node_end: int         # one past the last owned output node
+    num_relations: int    # R' (the root pseudo relation is id R')
+    tile: int
+    n_tiles: int
+    n_chunks: int
+    n_edges: int          # real edges placed (without root pseudo edges / padding)
+    tile_ptr: Tensor      # int32 [n_tiles + 1]
+    chunk_rel: Tensor     # int32 [n_chunks]
+    chunk_cnt: Tensor     # int32 [n_chunks]
+    chunk_tile: Tensor    # int32 [n_chunks]
+    rel_order: Tensor     # int32 [n_chunks]
+    slot_src: Tensor      # int32 [n_chunks * CHUNK]
+    slot_w: Tensor        # float32 [n_chunks * CHUNK]
+    slot_dstl: Tensor     # int32 [n_chunks * CHUNK]
+    _keep: tuple = field(default=(), repr=False)
+
+    @property
+    def device(self):
+        return self.slot_src.device
+
+    @property
+    def n_owned(self) -> int:
+        return self.node_end - self.node_begin
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (
+            self.tile_ptr, self.chunk_rel, self.chunk_cnt, self.chunk_tile, self.rel_order,
+            self.slot_src, self.slot_w, self.slot_dstl))
+
+
+def edge_weights(src: Tensor, dst: Tensor, rel: Tensor, num_relations: int, aggr: str = "mean") -> Tensor:
+    """w_e = 1 / max(1, c[dst_e, rel_e]) (duplicates counted), float32, in input edge order."""
+    if aggr in ("sum", "add"):
+        return torch.ones(dst.shape[0], dtype=torch.float32, device=dst.device)
+    if aggr != "mean":
+        raise ValueError(f"unsupported aggr {aggr!r}")
+    key = dst.to(torch.int64) * num_relations + rel.to(torch.int64)
+    skey, perm = torch.sort(key)
+    _, inv, cnt = torch.unique_consecutive(skey, return_inverse=True, return_counts=True)
+    w_sorted = 1.0 / cnt.to(torch.float32)[inv]
+    w = torch.empty_like(w_sorted)
+    w[perm] = w_sorted
+    return w
+
+
+def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes: int,
+               num_relations: int, tile: int, node_begin: int = 0,
+               node_end: Optional[int] = None) -> TilePlan:
+    """Lay out the edges scattering into ``[node_begin, node_end)``.
+
+    gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src).
+    """
+    if node_end is None:
+        node_end = n_nodes
+    if node_begin % tile != 0:
+        raise ValueError("node_begin must be a multiple of the tile size")
+    dev = gather.device
+    n_own = node_end - node_begin
+    r1 = num_relations + 1
+    gather = gather.to(torch.int64)
+    scatter = scatter.to(torch.int64)
+    rel = rel.to(torch.int64)
+    if rel.numel() and (int(rel.min()) < 0 or int(rel.max()) >= num_relations):
+        raise ValueError("edge_type out of range [0, num_relations)")
+    if gather.numel() and (int(gather.min()) < 0 or int(gather.max()) >= n_nodes
+                           or int(scatter.min()) < 0 or int(scatter.max()) >= n_nodes):
+        raise ValueError("edge_index out of range [0, num_nodes)")
+    own = (scatter >= node_begin) & (scatter < node_end)
+    if not bool(own.all()):
+        gather, scatter, rel, w = gather[own], scatter[own], rel[own], w[own]
+    n_edges = int(gather.shape[0])
+    # root pseudo edges: node i gathers its own row with weight 1 under relation id R'
+    nodes = torch.arange(node_begin, node_end, device=dev, dtype=torch.int64)
+    g_all = torch.cat([gather, nodes])
+    loc = torch.cat([scatter, nodes]) - node_begin
+    r_all = torch.cat([rel, torch.full((n_own,), num_relations, device=dev, dtype=torch.int64)])
+    w_all = torch.cat([w.to(torch.float32), torch.ones(n_own, device=dev, dtype=torch.float32)])
+    tile_id = loc // tile
+    dstl = loc - tile_id * tile
+    key = (tile_id * r1 + r_all) * tile + dstl
+    key, perm = torch.sort(key, stable=True)
+    g_all, w_all, dstl = g_all[perm], w_all[perm], dstl[perm]
+    gk = key // tile
+    gvals, gcnt = torch.unique_consecutive(gk, return_counts=True)
+    gch = (gcnt + (CHUNK - 1)) // CHUNK
+    chunk_base = torch.cumsum(gch, 0) - gch
+    n_chunks = int(gch.sum())
+    n_groups = gvals.shape[0]
+    gstart = torch.cumsum(gcnt, 0) - gcnt
+    grp_of_edge = torch.repeat_interleave(torch.arange(n_groups, device=dev), gcnt)
+    rank = torch.arange(key.shape[0], device=dev) - gstart[grp_of_edge]
+    slot = chunk_base[grp_of_edge] * CHUNK + rank
+    n_slots = n_chunks * CHUNK
+    slot_src = torch.full((n_slots,), -1, dtype=torch.int32, device=dev)
+    slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+    slot_dstl = torch.zeros(n_slots, dtype=torch.int32, device=dev)
+    slot_src[slot] = g_all.to(torch.int32)
+    slot_w[slot] = w_all
+    slot_dstl[slot] = dstl.to(torch.int32)
+    grp_of_chunk = torch.repeat_interleave(torch.arange(n_groups, device=dev), gch)
+    idx_in_grp = torch.arange(n_chunks, device=dev) - chunk_base[grp_of_chunk]
+    chunk_cnt = torch.clamp(gcnt[grp_of_chunk] - idx_in_grp * CHUNK, max=CHUNK).to(torch.int32)
+    chunk_rel = (gvals[grp_of_chunk] % r1).to(torch.int32)
+    chunk_tile = (gvals[grp_of_chunk] // r1).to(torch.int32)
+    n_tiles = (n_own + tile - 1) // tile
+    per_tile = torch.bincount(chunk_tile.to(torch.int64), minlength=n_tiles)
+    tile_ptr = torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev)
+    tile_ptr[1:] = torch.cumsum(per_tile, 0).to(torch.int32)
+    order_key = chunk_rel.to(torch.int64) * max(n_tiles, 1) + chunk_tile.to(torch.int64)
+    rel_order = torch.sort(order_key, stable=True)[1].to(torch.int32)
+    return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end,
+                    num_relations=num_relations, tile=tile, n_tiles=n_tiles, n_chunks=n_chunks,
+                    n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
+                    chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
+                    slot_dstl=slot_dstl)
+
+
+@dataclass
+class GraphPlans:
+    """Forward plan (edges grouped by destination) + transposed plan (grouped by source)."""
+    fwd: TilePlan
+    bwd: TilePlan
+    num_edges: int
+
+
+def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
+                      tile: int, aggr: str = "mean",
+                      fwd_range: Optional[Tuple[int, int]] = None,
+                      bwd_range: Optional[Tuple[int, int]] = None) -> GraphPlans:
+    src, dst = edge_index[0], edge_index[1]
+    w = edge_weights(src, dst, edge_type, num_relations, aggr)
+    fb, fe = fwd_range if fwd_range is not None else (0, n_nodes)
+    bb, be = bwd_range if bwd_range is not None else (0, n_nodes)
+    fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe)
+    bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be)
+    return GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(edge_type.shape[0]))
+
+
+def balanced_ranges(counts_per_tile: Tensor, world: int, tile: int, n_nodes: int):
+    """Cut the tile sequence into ``world`` contiguous node ranges of about equal edge count
+    (SURVEY.md 8e "ranges balanced by edge count").  Boundaries are multiples of ``tile`` so a
+    rank's tiles -- and therefore every accumulation order -- equal the single-rank ones."""
+    n_tiles = counts_per_tile.shape[0]
+    cum = torch.cumsum(counts_per_tile.to(torch.float64) + 1e-3, 0)  # +eps: spread empty tiles too
+    total = float(cum[-1]) if n_tiles else 0.0
+    bounds = [0]
+    for p in range(1, world):
+        t = int(torch.searchsorted(cum, torch.tensor(total * p / world, dtype=torch.float64,
+                                                      device=cum.device)).item())
+        t = min(max(t, bounds[-1]), n_tiles)
+        bounds.append(t)
+    bounds.append(n_tiles)
+    return [(min(b * tile, n_nodes), min(e * tile, n_nodes)) for b, e in zip(bounds[:-1], bounds[1:])]
+
+
+# ------------------------------------------------------------------------------------------
+# plan cache, keyed on the identity of the tensors the caller passes every forward
+# ------------------------------------------------------------------------------------------
+_CACHE: Dict[tuple, tuple] = {}
+_CACHE_MAX = 16
+
+
+def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
+                       tile: int, aggr: str, builder=None, extra_key=()) -> GraphPlans:
+    key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
+           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, aggr) + tuple(extra_key)
+    hit = _CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    if builder is None:
+        plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr)
+    else:
+        plans = builder()
+    if len(_CACHE) >= _CACHE_MAX:
+        _CACHE.pop(next(iter(_CACHE)))
+    # hold the key tensors so their storage (and data_ptr) cannot be recycled while cached
+    _CACHE[key] = (plans, edge_index, edge_type)
+    return plans
+
+
+def clear_plan_cache() -> None:
+    _CACHE.clear()

@@ -1,0 +1,45 @@
+"""numpy walk over a TilePlan exactly as the HIP kernels walk it (test helper, CPU only).
+
+fwd / dX kernel: for every chunk, rows = slots; out[tile*T + dstl] += w * (x[src] @ Wp[rel])
+dW kernel     : dWp[rel] += (w * x[src])^T @ g[tile*T + dstl]
+where Wp = concat(weight[R'], root[None]) -- the root is relation id R'."""
+import numpy as np
+
+from scaling_rgcn_training_amd.plan import CHUNK
+
+
+def _slots(plan):
+    src = plan.slot_src.cpu().numpy().astype(np.int64)
+    w = plan.slot_w.cpu().numpy().astype(np.float64)
+    dstl = plan.slot_dstl.cpu().numpy().astype(np.int64)
+    rel = np.repeat(plan.chunk_rel.cpu().numpy().astype(np.int64), CHUNK)
+    tile = np.repeat(plan.chunk_tile.cpu().numpy().astype(np.int64), CHUNK)
+    valid = src >= 0
+    node = tile * plan.tile + dstl  # local to node_begin
+    return src, w, rel, node, valid
+
+
+def emulate_spmm(plan, x, w_all, bias=None):
+    src, w, rel, node, valid = _slots(plan)
+    x = np.asarray(x, np.float64)
+    w_all = np.asarray(w_all, np.float64)
+    out = np.zeros((plan.n_owned, w_all.shape[2]))
+    if bias is not None:
+        out += np.asarray(bias, np.float64)[None, :]
+    for r in range(w_all.shape[0]):
+        sel = valid & (rel == r)
+        if sel.any():
+            np.add.at(out, node[sel], (x[src[sel]] * w[sel, None]) @ w_all[r])
+    return out
+
+
+def emulate_dw(plan, x, g_owned, n_rel_all, din, dout):
+    src, w, rel, node, valid = _slots(plan)
+    x = np.asarray(x, np.float64)
+    g = np.asarray(g_owned, np.float64)
+    dw = np.zeros((n_rel_all, din, dout))
+    for r in range(n_rel_all):
+        sel = valid & (rel == r)
+        if sel.any():
+            dw[r] = (x[src[sel]] * w[sel, None]).T @ g[node[sel]]
+    return dw

@@ -1,0 +1,138 @@
+"""Host logic: the graph plan (tile / chunk layout) reproduces the layer when walked the way
+the kernels walk it.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rgcn_oracle as O
+from scaling_rgcn_training_amd import plan as P
+from tests.plan_emulator import emulate_dw, emulate_spmm
+
+
+def _plans_from_golden(g, tile):
+    ei = torch.from_numpy(g["edge_index"]).long()
+    et = torch.from_numpy(g["edge_type"]).long()
+    return P.build_graph_plans(ei, et, int(g["num_nodes"]), int(g["num_relations"]), tile)
+
+
+def _check_invariants(plan, n_real_edges):
+    c = P.CHUNK
+    assert plan.slot_src.numel() == plan.n_chunks * c
+    src = plan.slot_src.view(-1, c)
+    cnt = plan.chunk_cnt.long()
+    col = torch.arange(c)[None, :]
+    assert torch.all((src >= 0) == (col < cnt[:, None]))          # valid slots are a prefix
+    assert torch.all(plan.slot_w.view(-1, c)[col >= cnt[:, None]] == 0)
+    assert int(cnt.sum()) == n_real_edges + plan.n_owned            # + one root pseudo edge per node
+    assert torch.all(plan.slot_dstl >= 0) and torch.all(plan.slot_dstl < plan.tile)
+    tp = plan.tile_ptr.long()
+    assert tp[0] == 0 and tp[-1] == plan.n_chunks and torch.all(tp[1:] > tp[:-1])
+    for t in range(plan.n_tiles):                                   # tile-major, rel ascending, root last
+        rels = plan.chunk_rel[tp[t]:tp[t + 1]]
+        assert torch.all(plan.chunk_tile[tp[t]:tp[t + 1]] == t)
+        assert torch.all(rels[1:] >= rels[:-1]) and rels[-1] == plan.num_relations
+    ro = plan.rel_order.long()
+    assert sorted(ro.tolist()) == list(range(plan.n_chunks))
+    assert torch.all(plan.chunk_rel[ro][1:] >= plan.chunk_rel[ro][:-1])
+
+
+@pytest.mark.parametrize("tile", [4, 64, 256])
+def test_plan_walk_matches_golden(golden, tile):
+    if str(golden["mode"]) != "full":
+        pytest.skip("plan is weight-mode independent")
+    if tile == 4 and golden["edge_index"].shape[1] > 2000:
+        pytest.skip("tiny tiles only on small graphs")
+    plans = _plans_from_golden(golden, tile)
+    e = golden["edge_index"].shape[1]
+    _check_invariants(plans.fwd, e)
+    _check_invariants(plans.bwd, e)
+    w_all = np.concatenate([golden["weight"], golden["root"][None]], 0).astype(np.float64)
+    out = emulate_spmm(plans.fwd, golden["x"], w_all, golden["bias"])
+    np.testing.assert_allclose(out, golden["out"], rtol=1e-6, atol=1e-6)
+    dx = emulate_spmm(plans.bwd, golden["dout"], np.transpose(w_all, (0, 2, 1)))
+    np.testing.assert_allclose(dx, golden["d_x"], rtol=1e-6, atol=1e-6)
+    dw = emulate_dw(plans.fwd, golden["x"], golden["dout"], w_all.shape[0], w_all.shape[1], w_all.shape[2])
+    np.testing.assert_allclose(dw[:-1], golden["d_wfull"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dw[-1], golden["d_root"], rtol=1e-6, atol=1e-6)
+
+
+def test_edge_weights_mean_and_sum():
+    src = torch.tensor([0, 1, 1, 2, 3, 3])
+    dst = torch.tensor([2, 2, 2, 0, 2, 2])
+    rel = torch.tensor([0, 0, 0, 1, 1, 0])
+    w = P.edge_weights(src, dst, rel, 2, "mean")
+    assert torch.allclose(w, torch.tensor([0.25, 0.25, 0.25, 1.0, 1.0, 0.25]))
+    assert torch.all(P.edge_weights(src, dst, rel, 2, "sum") == 1)
+
+
+def test_empty_graph_and_isolated_nodes():
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    et = torch.zeros(0, dtype=torch.long)
+    plans = P.build_graph_plans(ei, et, 7, 3, 4)
+    _check_invariants(plans.fwd, 0)
+    assert plans.fwd.n_tiles == 2 and plans.fwd.n_chunks == 2
+    x = np.random.default_rng(0).normal(size=(7, 5))
+    w_all = np.random.default_rng(1).normal(size=(4, 5, 3))
+    out = emulate_spmm(plans.fwd, x, w_all, np.zeros(3))
+    np.testing.assert_allclose(out, x @ w_all[-1], rtol=1e-12)
+
+
+def test_hub_spans_many_chunks():
+    n, e = 50, 1000
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.full((e,), 7)
+    typ = torch.randint(0, 2, (e,), generator=g)
+    ei = torch.stack([src, dst])
+    plans = P.build_graph_plans(ei, typ, n, 3, 16)
+    _check_invariants(plans.fwd, e)
+    assert plans.fwd.n_chunks > e // P.CHUNK
+    w, root, bias = O.synthetic_params(3, 6, 4)
+    x = torch.randn(n, 6, generator=g)
+    ref = O.rgcn_conv_dense(x.numpy(), ei.numpy(), typ.numpy(), w.numpy(), root.numpy(), bias.numpy())
+    w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0)
+    np.testing.assert_allclose(emulate_spmm(plans.fwd, x.numpy(), w_all, bias.numpy()), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_out_of_range_inputs_raise():
+    ei = torch.tensor([[0, 5], [1, 2]])
+    with pytest.raises(ValueError):
+        P.build_graph_plans(ei, torch.tensor([0, 0]), 4, 2, 4)
+    with pytest.raises(ValueError):
+        P.build_graph_plans(torch.tensor([[0, 1], [1, 2]]), torch.tensor([0, 2]), 4, 2, 4)
+
+
+def test_node_range_plans_tile_aligned_partition():
+    ei, et = O.synthetic_graph(1000, 8000, 5, seed=2)
+    tile = 64
+    w = P.edge_weights(ei[0], ei[1], et, 5)
+    full = P.build_plan(ei[0], ei[1], et, w, 1000, 5, tile)
+    counts = torch.bincount(ei[1] // tile, minlength=full.n_tiles)
+    ranges = P.balanced_ranges(counts, 3, tile, 1000)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 1000
+    assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+    assert all(b % tile == 0 for b, _ in ranges)
+    x = np.random.default_rng(0).normal(size=(1000, 8))
+    w_all = np.random.default_rng(1).normal(size=(6, 8, 4))
+    ref = emulate_spmm(full, x, w_all)
+    parts = []
+    for b, e_ in ranges:
+        p = P.build_plan(ei[0], ei[1], et, w, 1000, 5, tile, b, e_)
+        parts.append(emulate_spmm(p, x, w_all))
+        # a rank's chunks are exactly the single-rank chunks of its tiles
+        t0, t1 = b // tile, (e_ + tile - 1) // tile
+        c0, c1 = int(full.tile_ptr[t0]), int(full.tile_ptr[t1])
+        assert torch.equal(p.slot_src, full.slot_src[c0 * P.CHUNK:c1 * P.CHUNK])
+        assert torch.equal(p.slot_w, full.slot_w[c0 * P.CHUNK:c1 * P.CHUNK])
+    np.testing.assert_allclose(np.concatenate(parts, 0), ref, rtol=1e-12, atol=1e-12)
+
+
+def test_plan_cache_identity():
+    ei, et = O.synthetic_graph(100, 500, 3, seed=1)
+    P.clear_plan_cache()
+    a = P.cached_graph_plans(ei, et, 100, 3, 16, "mean")
+    b = P.cached_graph_plans(ei, et, 100, 3, 16, "mean")
+    assert a is b
+    ei2 = ei.clone()
+    c = P.cached_graph_plans(ei2, et, 100, 3, 16, "mean")
+    assert c is not a
