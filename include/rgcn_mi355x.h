@@ -1,0 +1,114 @@
+/*
+ * rgcn_mi355x.h -- C ABI of librgcn_mi355x.so: the R-GCN layer hot path (forward + backward of
+ * the per-relation sparse message passing  out = sum_r D_r^-1 A_r X W_r + X root + b) as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *   - the arithmetic of torch_geometric.nn.RGCNConv (torch_geometric==2.3.1, requirements.txt:7),
+ *     which the reference reaches from model/layers.py:21,23 (Emb_Layers.forward), :62,64
+ *     (Emb_ATT_Layers.forward) and :108,110 (Emb_MLP_Layers.forward), and differentiates through at
+ *     model/modelTrainer.py:66 (output.backward()).
+ * The reference has no FFI of its own (it is pure Python); INTEGRATION.md shows the ctypes stub a
+ * maintainer would add.
+ *
+ * Conventions (SURVEY.md 8b "C ABI"):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - every function returns an int status (0 = RGCN_OK, negative = argument error, positive =
+ *     hipError_t of a failed launch); nothing throws;
+ *   - nothing allocates: workspaces are sized by the *_bytes / *_floats queries and owned by the caller;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); no host synchronisation, no global mutable state -> re-entrant on distinct streams
+ *     and capturable into a hipGraph.
+ *   - float32 features, int32 indices.  Feature row strides (ld*) are in ELEMENTS, must be multiples
+ *     of 4 (16-byte rows) and >= the feature width; columns between the width and the width rounded
+ *     up to a multiple of 4 must hold zeros (the Python host pads when needed).
+ *   - feature widths 1..128 per side.
+ */
+#ifndef RGCN_MI355X_H
+#define RGCN_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGCN_ABI_VERSION 1
+#define RGCN_CHUNK 64 /* edge slots per chunk == rows of one LDS ring slot */
+#define RGCN_MAX_WIDTH 128
+
+enum rgcn_status {
+    RGCN_OK = 0,
+    RGCN_ERR_NULL = -1,      /* a required pointer is NULL */
+    RGCN_ERR_WIDTH = -2,     /* feature width outside 1..128 */
+    RGCN_ERR_STRIDE = -3,    /* a row stride is not a multiple of 4 or smaller than the width */
+    RGCN_ERR_PLAN = -4,      /* inconsistent plan (sizes <= 0, tile not a multiple of 16, ...) */
+    RGCN_ERR_LDS = -5,       /* plan tile too large for the 160 KiB LDS at these widths */
+    RGCN_ERR_WORKSPACE = -6, /* workspace smaller than the *_workspace_bytes query */
+    RGCN_ERR_DEVICE = -7     /* current device is not gfx950 / no device */
+};
+
+/* Graph plan in HBM, built once per graph (scaling_rgcn_training_amd/plan.py documents the layout;
+ * PyG rebuilds the per-relation masks and counts on every forward call instead).
+ * Rows scattered into are the plan's OWNED node range, numbered from 0 (= node_begin). */
+typedef struct rgcn_plan {
+    int32_t n_nodes;       /* rows of the gathered matrix (whole graph) */
+    int32_t n_owned;       /* output rows (node_end - node_begin) */
+    int32_t num_relations; /* R'; the self-loop ("root") is relation id R' */
+    int32_t tile;          /* output nodes per tile (multiple of 16) */
+    int32_t n_tiles;
+    int32_t n_chunks;
+    const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
+    const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */
+    const int32_t* chunk_cnt;  /* [n_chunks] valid slots (1..64), a prefix of the chunk */
+    const int32_t* chunk_tile; /* [n_chunks] */
+    const int32_t* rel_order;  /* [n_chunks] chunk ids sorted by (relation, tile) */
+    const int32_t* slot_src;   /* [n_chunks * 64] row to gather, -1 = padding */
+    const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */
+    const int32_t* slot_dstl;  /* [n_chunks * 64] row inside the tile */
+} rgcn_plan_t;
+
+int rgcn_abi_version(void);
+const char* rgcn_status_string(int status);
+
+/* Widths are padded to 16/32/64/128 inside the kernels; returns that padded value (0 if unsupported). */
+int rgcn_padded_width(int width);
+
+/* Floats of the MFMA-fragment-ordered weight pack: (R' + 1) * pad(K) * pad(N). */
+size_t rgcn_packed_weight_floats(int num_relations, int din, int dout);
+
+/* Pack weight[R', din, dout] (+ root[din, dout], may be NULL = zeros) into B-fragment order.
+ * transpose = 0: B_r = W_r (K = din, N = dout), used by rgcn_fwd;
+ * transpose = 1: B_r = W_r^T (K = dout, N = din), used by rgcn_bwd_dx.
+ * Replaces nothing in PyG (it indexes weight[i] directly); cost O(R' * din * dout) per call. */
+int rgcn_pack_weights(const float* weight, const float* root, int num_relations, int din, int dout,
+                      int transpose, float* packed, void* stream);
+
+/* Forward of RGCNConv.forward (aggr mean/sum folded into the plan's edge weights):
+ *   out[i, :] = bias + sum_{slots scattering into i} w_e * x[src_e, :] @ W_{rel_e}   (root = rel R')
+ * x: [plan->n_nodes, ldx]; out: [plan->n_owned, ldo]; packed_w from rgcn_pack_weights(transpose=0);
+ * bias: [dout] or NULL.  Columns dout..roundup4(dout) of out are written as zeros. */
+int rgcn_fwd(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* packed_w,
+             const float* bias, float* out, int ldo, int dout, void* stream);
+
+/* dX of the layer (autograd of index_select/scatter-mean/matmul in PyG's loop), atomics-free:
+ *   dx[j, :] = sum_{edges j->i, r} w_e * g[i, :] @ W_r^T + g[j, :] @ root^T
+ * `plan_t` is the TRANSPOSED plan (edges grouped by source); g: [plan_t->n_nodes, ldg] upstream
+ * gradient; packed_wt from rgcn_pack_weights(transpose=1); dx: [plan_t->n_owned, lddx]. */
+int rgcn_bwd_dx(const rgcn_plan_t* plan_t, const float* g, int ldg, int dout, const float* packed_wt,
+                float* dx, int lddx, int din, void* stream);
+
+/* Weight gradients: d_weight[r] = H_r^T g, d_root = X^T g, d_bias = column sums of g, over the
+ * plan's owned rows (g: [plan->n_owned, ldg] is the upstream gradient of those rows).
+ * Any of d_weight / d_root / d_bias may be NULL (frozen parameter, model/layers.py:33-46).
+ * Deterministic: per-workgroup partial slabs in `workspace` are summed in a fixed order. */
+size_t rgcn_bwd_dw_workspace_bytes(const rgcn_plan_t* plan, int din, int dout);
+int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* g, int ldg,
+                int dout, void* workspace, size_t workspace_bytes, float* d_weight, float* d_root,
+                float* d_bias, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGCN_MI355X_H */

@@ -1,0 +1,139 @@
+"""ctypes binding of librgcn_mi355x.so (C ABI: include/rgcn_mi355x.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, an exception is
+raised.  The library is built in-tree by ``__graft_entry__.build()`` / ``tools/build_lib.sh``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgcn_mi355x.so")
+ABI_VERSION = 1
+
+EXPORTS = (
+    "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
+    "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
+)
+
+
+class RgcnPlanStruct(C.Structure):
+    """struct rgcn_plan of include/rgcn_mi355x.h"""
+    _fields_ = [
+        ("n_nodes", C.c_int32), ("n_owned", C.c_int32), ("num_relations", C.c_int32),
+        ("tile", C.c_int32), ("n_tiles", C.c_int32), ("n_chunks", C.c_int32),
+        ("tile_ptr", C.c_void_p), ("chunk_rel", C.c_void_p), ("chunk_cnt", C.c_void_p),
+        ("chunk_tile", C.c_void_p), ("rel_order", C.c_void_p), ("slot_src", C.c_void_p),
+        ("slot_w", C.c_void_p), ("slot_dstl", C.c_void_p),
+    ]
+
+
+class RgcnLibraryError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library once; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RgcnLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the R-GCN layer.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.rgcn_abi_version.restype = i32
+    lib.rgcn_abi_version.argtypes = []
+    lib.rgcn_status_string.restype = C.c_char_p
+    lib.rgcn_status_string.argtypes = [i32]
+    lib.rgcn_padded_width.restype = i32
+    lib.rgcn_padded_width.argtypes = [i32]
+    lib.rgcn_packed_weight_floats.restype = sz
+    lib.rgcn_packed_weight_floats.argtypes = [i32, i32, i32]
+    lib.rgcn_pack_weights.restype = i32
+    lib.rgcn_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.rgcn_fwd.restype = i32
+    lib.rgcn_fwd.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, vp, vp, i32, i32, vp]
+    lib.rgcn_bwd_dx.restype = i32
+    lib.rgcn_bwd_dx.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, vp, i32, i32, vp]
+    lib.rgcn_bwd_dw_workspace_bytes.restype = sz
+    lib.rgcn_bwd_dw_workspace_bytes.argtypes = [C.POINTER(RgcnPlanStruct), i32, i32]
+    lib.rgcn_bwd_dw.restype = i32
+    lib.rgcn_bwd_dw.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, i32, i32, vp, sz, vp, vp, vp, vp]
+    if lib.rgcn_abi_version() != ABI_VERSION:
+        raise RgcnLibraryError(f"ABI version mismatch: library {lib.rgcn_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().rgcn_status_string(status).decode()
+        raise RgcnLibraryError(f"{what} failed with status {status}: {msg}")
+
+
+def plan_struct(plan) -> RgcnPlanStruct:
+    """Fill the C struct from a plan.TilePlan whose tensors live on the GPU."""
+    if plan.slot_src.device.type != "cuda":
+        raise RgcnLibraryError("the graph plan must live on the GPU (plan tensors are on %s)" % plan.slot_src.device)
+    return RgcnPlanStruct(
+        plan.n_nodes, plan.n_owned, plan.num_relations, plan.tile, plan.n_tiles, plan.n_chunks,
+        plan.tile_ptr.data_ptr(), plan.chunk_rel.data_ptr(), plan.chunk_cnt.data_ptr(),
+        plan.chunk_tile.data_ptr(), plan.rel_order.data_ptr(), plan.slot_src.data_ptr(),
+        plan.slot_w.data_ptr(), plan.slot_dstl.data_ptr())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def padded_width(w: int) -> int:
+    return load().rgcn_padded_width(int(w))
+
+
+# ---- thin typed wrappers: device tensors in, device tensors out, current torch stream ------------
+def pack_weights(weight: torch.Tensor, root: Optional[torch.Tensor], transpose: bool) -> torch.Tensor:
+    lib = load()
+    r, din, dout = weight.shape
+    n = lib.rgcn_packed_weight_floats(r, din, dout)
+    if n == 0:
+        raise RgcnLibraryError(f"unsupported layer widths {din}->{dout} (1..128 per side)")
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    check(lib.rgcn_pack_weights(weight.data_ptr(), _ptr(root), r, din, dout, int(transpose),
+                                packed.data_ptr(), _stream()), "rgcn_pack_weights")
+    return packed
+
+
+def fwd(ps: RgcnPlanStruct, x: torch.Tensor, din: int, packed: torch.Tensor,
+        bias: Optional[torch.Tensor], out: torch.Tensor, dout: int) -> None:
+    check(load().rgcn_fwd(C.byref(ps), x.data_ptr(), x.stride(0), din, packed.data_ptr(), _ptr(bias),
+                          out.data_ptr(), out.stride(0), dout, _stream()), "rgcn_fwd")
+
+
+def bwd_dx(ps_t: RgcnPlanStruct, g: torch.Tensor, dout: int, packed_t: torch.Tensor,
+           dx: torch.Tensor, din: int) -> None:
+    check(load().rgcn_bwd_dx(C.byref(ps_t), g.data_ptr(), g.stride(0), dout, packed_t.data_ptr(),
+                             dx.data_ptr(), dx.stride(0), din, _stream()), "rgcn_bwd_dx")
+
+
+def bwd_dw(ps: RgcnPlanStruct, x: torch.Tensor, din: int, g: torch.Tensor, dout: int,
+           d_weight: Optional[torch.Tensor], d_root: Optional[torch.Tensor],
+           d_bias: Optional[torch.Tensor]) -> None:
+    lib = load()
+    nbytes = lib.rgcn_bwd_dw_workspace_bytes(C.byref(ps), din, dout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib.rgcn_bwd_dw(C.byref(ps), x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0), dout,
+                          ws.data_ptr(), nbytes, _ptr(d_weight), _ptr(d_root), _ptr(d_bias), _stream()),
+          "rgcn_bwd_dw")

@@ -1,0 +1,256 @@
+"""``RGCNConv``: constructor-, attribute- and forward-compatible with PyG 2.3.1
+``torch_geometric.nn.RGCNConv`` as the reference uses it (/root/reference/model/layers.py:15-16,
+21-23, 33-46), with forward and backward running as the HIP kernels of
+``csrc/rgcn_kernels.hip`` through the C ABI of ``include/rgcn_mi355x.h``.
+
+Mutability contract (model/layers.py:33-46, model/modelTrainer.py:26-39): ``weight`` / ``root`` /
+``bias`` are plain ``nn.Parameter`` attributes that callers REPLACE after construction and may
+freeze; forward reads them at call time and backward skips the frozen ones.
+
+There is no CPU path: CPU tensors (or a missing HIP library) raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .plan import GraphPlans, TilePlan, cached_graph_plans
+
+
+def _round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def _rows16(t: Tensor, width: int) -> Tensor:
+    """float32, contiguous rows whose stride is a multiple of 4 elements, zero padded (C ABI rule)."""
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    if width % 4 != 0:
+        return torch.nn.functional.pad(t, (0, _round4(width) - width))
+    return t.contiguous()
+
+
+def tile_for(in_channels: int, out_channels: int) -> int:
+    """Output nodes per tile: the tile accumulator [tile, pad(width)] fp32 shares the 160 KiB LDS with
+    the DMA ring; both directions (forward: width = out, dX: width = in) use the same tile so one
+    pair of plans serves a layer."""
+    widest = max(_lib.padded_width(in_channels), _lib.padded_width(out_channels))
+    if widest == 0:
+        raise ValueError(f"RGCNConv widths must be in 1..128, got {in_channels}->{out_channels}")
+    return 128 if widest == 128 else 256
+
+
+class DistContext:
+    """One process per GPU; output nodes cut into equal tile-aligned ranges (see dist.py)."""
+
+    def __init__(self, group, rank: int, world: int, rows_per_rank: int):
+        self.group, self.rank, self.world, self.rows_per_rank = group, rank, world, rows_per_rank
+
+    def node_range(self, n_nodes: int) -> Tuple[int, int]:
+        b = min(self.rank * self.rows_per_rank, n_nodes)
+        e = min(b + self.rows_per_rank, n_nodes)
+        return b, e
+
+
+class _RGCNLayerFn(torch.autograd.Function):
+    """out = sum_r mean-aggregate_r(x) @ W_r + x @ root + bias   (forward: rgcn_fwd;
+    backward: rgcn_bwd_dx on the transposed plan + rgcn_bwd_dw)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w_full: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
+                plans: GraphPlans, dctx: Optional[DistContext]):
+        n, din = x.shape
+        num_rel, _, dout = w_full.shape
+        fp: TilePlan = plans.fwd
+        xp = _rows16(x, din)
+        wf = w_full.detach().float().contiguous()
+        rt = None if root is None else root.detach().float().contiguous()
+        bs = None if bias is None else bias.detach().float().contiguous()
+        packed = _lib.pack_weights(wf, rt, transpose=False)
+        ldo = _round4(dout)
+        if dctx is None:
+            out = torch.empty(n, ldo, dtype=torch.float32, device=x.device)
+            _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, out, dout)
+        else:
+            # every rank computes its own node range straight into its slice of the gathered buffer;
+            # with destination-range ownership the per-layer all-reduce of SURVEY.md 8e degenerates to
+            # this all-gather (each row has exactly one non-zero contributor)
+            rows = dctx.rows_per_rank
+            full = torch.empty(dctx.world * rows, ldo, dtype=torch.float32, device=x.device)
+            mine = full[dctx.rank * rows:(dctx.rank + 1) * rows]
+            if fp.n_owned > 0:
+                _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, mine, dout)
+            torch.distributed.all_gather_into_tensor(full, mine, group=dctx.group)
+            out = full[:n]
+        ctx.plans, ctx.dctx = plans, dctx
+        ctx.dims = (n, din, dout, num_rel)
+        ctx.has_root, ctx.has_bias = root is not None, bias is not None
+        ctx.save_for_backward(xp, wf, rt)
+        return out if ldo == dout else out[:, :dout]
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        xp, wf, rt = ctx.saved_tensors
+        plans, dctx = ctx.plans, ctx.dctx
+        n, din, dout, num_rel = ctx.dims
+        need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
+        gp = _rows16(g, dout)
+        dx = dw = droot = dbias = None
+        if need_x:
+            bp: TilePlan = plans.bwd
+            packed_t = _lib.pack_weights(wf, rt, transpose=True)
+            ldx = _round4(din)
+            if dctx is None:
+                dxp = torch.empty(n, ldx, dtype=torch.float32, device=g.device)
+                _lib.bwd_dx(_lib.plan_struct(bp), gp, dout, packed_t, dxp, din)
+            else:
+                rows = dctx.rows_per_rank
+                full = torch.empty(dctx.world * rows, ldx, dtype=torch.float32, device=g.device)
+                mine = full[dctx.rank * rows:(dctx.rank + 1) * rows]
+                if bp.n_owned > 0:
+                    _lib.bwd_dx(_lib.plan_struct(bp), gp, dout, packed_t, mine, din)
+                torch.distributed.all_gather_into_tensor(full, mine, group=dctx.group)
+                dxp = full[:n]
+            dx = dxp if ldx == din else dxp[:, :din]
+        need_root = need_root and ctx.has_root
+        need_bias = need_bias and ctx.has_bias
+        if need_w or need_root or need_bias:
+            fp: TilePlan = plans.fwd
+            dev = g.device
+            dw = torch.zeros(num_rel, din, dout, dtype=torch.float32, device=dev) if need_w else None
+            droot = torch.zeros(din, dout, dtype=torch.float32, device=dev) if need_root else None
+            dbias = torch.zeros(dout, dtype=torch.float32, device=dev) if need_bias else None
+            if fp.n_owned > 0:
+                g_own = gp[fp.node_begin:fp.node_end]
+                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, g_own, dout, dw, droot, dbias)
+            if dctx is not None:
+                for t in (dw, droot, dbias):
+                    if t is not None:
+                        torch.distributed.all_reduce(t, group=dctx.group)
+        return dx, dw, droot, dbias, None, None
+
+
+def rgcn_conv_function(x: Tensor, w_full: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
+                       plans: GraphPlans, dctx: Optional[DistContext] = None) -> Tensor:
+    if x.device.type != "cuda":
+        raise RuntimeError("RGCNConv runs only on an MI355X (ROCm 'cuda' device); there is no CPU fallback")
+    _lib.load()
+    return _RGCNLayerFn.apply(x, w_full, root, bias, plans, dctx)
+
+
+def glorot_(t: Tensor) -> Tensor:
+    """PyG ``glorot``: U(+-sqrt(6 / (size(-2) + size(-1))))"""
+    bound = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        return t.uniform_(-bound, bound)
+
+
+class RGCNConv(nn.Module):
+    r"""Drop-in for ``torch_geometric.nn.RGCNConv`` (PyG 2.3.1):
+
+    ``RGCNConv(in_channels, out_channels, num_relations, num_bases=None, num_blocks=None,
+    aggr='mean', root_weight=True, is_sorted=False, bias=True)``;
+    ``forward(x[N,in] f32, edge_index[2,E] int64, edge_type[E] int64) -> [N,out] f32``.
+
+    Parameters (registered in PyG's order): ``weight`` ``[R,in,out]`` (``[B,in,out]`` with
+    ``num_bases=B``; ``[R,nb,in/nb,out/nb]`` with ``num_blocks=nb``), ``comp`` ``[R,B]`` or ``None``,
+    ``root`` ``[in,out]`` or ``None``, ``bias`` ``[out]`` or ``None``.
+    """
+
+    def __init__(self, in_channels: int, out_channels: int, num_relations: int,
+                 num_bases: Optional[int] = None, num_blocks: Optional[int] = None, aggr: str = "mean",
+                 root_weight: bool = True, is_sorted: bool = False, bias: bool = True, **kwargs):
+        super().__init__()
+        if num_bases is not None and num_blocks is not None:
+            raise ValueError("Can not apply both basis-decomposition and block-diagonal-decomposition "
+                             "at the same time.")
+        if isinstance(in_channels, (tuple, list)):
+            if in_channels[0] != in_channels[1]:
+                raise NotImplementedError("bipartite RGCNConv is not used by the reference and not built")
+            in_channels = in_channels[0]
+        if aggr not in ("mean", "sum", "add"):
+            raise ValueError(f"unsupported aggr {aggr!r} (mean / sum)")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.num_relations = num_relations
+        self.num_bases = num_bases
+        self.num_blocks = num_blocks
+        self.aggr = "sum" if aggr == "add" else aggr
+        self.is_sorted = is_sorted  # only meaningful for PyG's pyg_lib path; plans are order-independent
+        self.dist: Optional[DistContext] = None
+        self._dist_plans = None
+        if num_bases is not None:
+            self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
+            self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
+        elif num_blocks is not None:
+            assert in_channels % num_blocks == 0 and out_channels % num_blocks == 0, \
+                "in_channels and out_channels must be divisible by num_blocks"
+            self.weight = nn.Parameter(torch.empty(num_relations, num_blocks, in_channels // num_blocks,
+                                                   out_channels // num_blocks))
+            self.register_parameter("comp", None)
+        else:
+            self.weight = nn.Parameter(torch.empty(num_relations, in_channels, out_channels))
+            self.register_parameter("comp", None)
+        if root_weight:
+            self.root = nn.Parameter(torch.empty(in_channels, out_channels))
+        else:
+            self.register_parameter("root", None)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        tile_for(in_channels, out_channels)  # validates the widths early
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        glorot_(self.weight)
+        if self.comp is not None:
+            glorot_(self.comp)
+        if self.root is not None:
+            glorot_(self.root)
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+
+    def effective_weight(self) -> Tensor:
+        """Dense ``[R, in, out]`` relation weights (differentiable torch ops; O(R*in*out), tiny next to
+        the edge work).  Basis: ``(comp @ weight.view(B,-1)).view(R,in,out)``; block-diagonal: blocks
+        placed on the diagonal of a zero matrix."""
+        if self.num_bases is not None:
+            return (self.comp @ self.weight.view(self.num_bases, -1)).view(
+                self.num_relations, self.in_channels, self.out_channels)
+        if self.num_blocks is not None:
+            nb = self.num_blocks
+            bi, bo = self.in_channels // nb, self.out_channels // nb
+            eye = torch.eye(nb, device=self.weight.device, dtype=self.weight.dtype)
+            # [R, nb, bi, bo] -> [R, nb, bi, nb, bo] with zeros off the block diagonal
+            w = torch.einsum("rbio,bc->rbico", self.weight, eye)
+            return w.reshape(self.num_relations, self.in_channels, self.out_channels)
+        return self.weight
+
+    def _plans(self, x: Tensor, edge_index: Tensor, edge_type: Tensor) -> GraphPlans:
+        n = x.shape[0]
+        tile = tile_for(self.in_channels, self.out_channels)
+        if self.dist is None:
+            return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr)
+        from .dist import cached_rank_plans
+        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist)
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None) -> Tensor:
+        assert edge_type is not None, "edge_type is required (PyG RGCNConv asserts the same)"
+        if x is None or not torch.is_floating_point(x):
+            raise NotImplementedError("featureless (integer / None x) RGCNConv is never used by the reference "
+                                      "(x is always float: model/layers.py:21,62,108) and is not built")
+        if x.dim() != 2 or x.shape[1] != self.in_channels:
+            raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
+        plans = self._plans(x, edge_index, edge_type)
+        return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, "
+                f"num_relations={self.num_relations})")

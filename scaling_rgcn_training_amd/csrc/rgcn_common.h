@@ -1,0 +1,94 @@
+// rgcn_common.h -- device helpers shared by the gfx950 R-GCN kernels.
+//
+// Execution model of every hot kernel in this library (DESIGN.md "Kernels"):
+//   one 512-thread workgroup per CU = 4 PRODUCER waves + 4 CONSUMER waves (one of each per SIMD);
+//   producers gather feature rows by index straight into an LDS ring with LDS-DMA
+//   (global_load_lds_dwordx4: per-lane source address, linear LDS destination), several ring slots
+//   ahead, behind a COUNTED s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain
+//   the DMA queue); consumers read MFMA fragments from the ring with ds_read_b128/b32 and run
+//   v_mfma_f32_16x16x4_f32 (exact fp32).  Row indices reach the producers through scalar loads
+//   (lgkmcnt), so no ordinary vector load ever sits in the DMA queue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rgcn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunk = 64;          // edge slots per chunk (== RGCN_CHUNK)
+constexpr int kThreads = 512;       // 8 waves: 0-3 producers, 4-7 consumers
+constexpr int kProducerWaves = 4;
+constexpr int kLdsBytes = 160 * 1024;
+
+// 16 bytes of zeros: where a DMA lane points when its slot is padding or its column chunk lies
+// beyond the feature width (LDS-DMA cannot be predicated per lane without changing the vmcnt count).
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void wg_barrier() {
+    // consumers: make sure their LDS reads/atomics have retired; producers: nothing pending on lgkm
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// LDS-DMA: 16 B per lane from `gptr` (per lane) to lds_base + lane*16 (lds_base wave-uniform).
+__device__ __forceinline__ void dma16(const float* gptr, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+// 4 B per lane to lds_base + lane*4.
+__device__ __forceinline__ void dma4(const void* gptr, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
+}
+
+// element `idx` (0..15) of sixteen wave-uniform ints held as 4 x int4 (SGPRs after s_load_dwordx16).
+// A select tree, never an array: runtime-indexed arrays go to scratch.
+__device__ __forceinline__ int pick16(int idx, int4 q0, int4 q1, int4 q2, int4 q3) {
+    const bool b3 = idx & 8, b2 = idx & 4, b1 = idx & 2, b0 = idx & 1;
+    const int ax = b3 ? (b2 ? q3.x : q2.x) : (b2 ? q1.x : q0.x);
+    const int ay = b3 ? (b2 ? q3.y : q2.y) : (b2 ? q1.y : q0.y);
+    const int az = b3 ? (b2 ? q3.z : q2.z) : (b2 ? q1.z : q0.z);
+    const int aw = b3 ? (b2 ? q3.w : q2.w) : (b2 ? q1.w : q0.w);
+    const int lo = b1 ? az : ax;
+    const int hi = b1 ? aw : ay;
+    return b0 ? hi : lo;
+}
+
+// XOR swizzle of the 16-byte column position inside a ring row (applied on the DMA SOURCE address and
+// on the read; the LDS image itself stays lane-linear as LDS-DMA requires).
+//   kRowRead  : rows are read 16 at a time with ds_read_b128 (A operand of H @ W)        -> f(r) = r
+//   kColRead  : 4 consecutive rows are read per ds_read_b32 (both operands of H^T @ G)   -> f(r) = rot2(r)
+enum SwizzleMode { kRowRead = 0, kColRead = 1 };
+template <int MODE, int LPR>
+__device__ __forceinline__ int swizzle(int row) {
+    constexpr int mask = (LPR - 1) < 15 ? (LPR - 1) : 15;
+    if (MODE == kRowRead) return row & mask;
+    return (((row & 3) << 2) | ((row >> 2) & 3)) & mask;
+}
+
+// Wave-uniform metadata loads.  Reading through the CONSTANT address space makes hipcc emit scalar
+// loads (s_load_*, lgkmcnt) even after the kernel has issued LDS-DMA or stores; a plain global read
+// would be re-classified as clobberable, become a vector load and put a compiler-inserted
+// s_waitcnt vmcnt(0) in front of its first use -- draining the DMA ring the producers keep in flight.
+// Valid because the plan arrays are never written while a kernel that reads them runs.
+typedef const __attribute__((address_space(4))) int c_int;
+typedef const __attribute__((address_space(4))) i32x4 c_i32x4;
+__device__ __forceinline__ int ldc(const int* p, long idx) { return ((c_int*)(uintptr_t)p)[idx]; }
+__device__ __forceinline__ int4 ldc4(const int* p, long idx4) {
+    const i32x4 v = ((c_i32x4*)(uintptr_t)p)[idx4];
+    return make_int4(v[0], v[1], v[2], v[3]);
+}
+
+__host__ __device__ inline int padded_width(int w) {
+    if (w < 1 || w > 128) return 0;
+    return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 64 : 128));
+}
+
+}  // namespace rgcn

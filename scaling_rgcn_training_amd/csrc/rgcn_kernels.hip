@@ -1,0 +1,678 @@
+// rgcn_kernels.hip -- R-GCN layer forward / backward for gfx950 (MI355X) and the C ABI of
+// include/rgcn_mi355x.h.  Written for CDNA4 only: 64-wide waves, LDS-DMA gathers, fp32 MFMA.
+//
+// Replaces the arithmetic of torch_geometric.nn.RGCNConv (PyG 2.3.1) that the reference calls at
+// /root/reference/model/layers.py:21,23,62,64,108,110 and differentiates at model/modelTrainer.py:66.
+//
+// Kernels
+//   rgcn_pack_kernel      weight[R',din,dout] (+root) -> MFMA B-fragment order, zero padded to 16/32/64/128
+//   rgcn_tile_kernel      forward AND dX: per output tile, out_tile(LDS) += w_e * (x[src_e] @ B_rel)
+//                         (tile-major walk of the plan; dX = same kernel on the transposed plan with W^T)
+//   rgcn_dw_kernel        weight gradients: per relation, dB_rel += (w_e x[src_e])^T g[dst_e]
+//                         (relation-major walk; register accumulators; one partial slab per (workgroup, rel))
+//   rgcn_dw_reduce_kernel fixed-order sum of the slabs -> d_weight / d_root / d_bias
+#include "rgcn_common.h"
+#include "../../include/rgcn_mi355x.h"
+
+namespace rgcn {
+
+// ------------------------------------------------------------------------------------------------
+// weight pack
+// ------------------------------------------------------------------------------------------------
+// packed[((rel*NT + s)*KT + j)*256 + lane*4 + t] = B_rel[k = 16j + 4*(lane>>4) + t][col = 16s + (lane&15)]
+// which is exactly the (a, b) pairing the consumers use for v_mfma_f32_16x16x4_f32:
+// lane l supplies A[row = l&15][k' = l>>4] and B[k' = l>>4][col = l&15]; MFMA step (j,t) stands for
+// k = 16j + 4k' + t on both operands.
+__global__ void rgcn_pack_kernel(const float* __restrict__ weight, const float* __restrict__ root, int num_rel,
+                                 int din, int dout, int transpose, int KP, int NP, float* __restrict__ packed) {
+    const int per_rel = KP * NP;
+    const long total = (long)(num_rel + 1) * per_rel;
+    const int KT = KP / 16, NT = NP / 16;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int rel = (int)(idx / per_rel);
+        int rem = (int)(idx % per_rel);
+        const int t = rem & 3;
+        const int lane = (rem >> 2) & 63;
+        rem >>= 8;
+        const int j = rem % KT;
+        const int s = rem / KT;
+        (void)NT;
+        const int k = 16 * j + 4 * (lane >> 4) + t;
+        const int col = 16 * s + (lane & 15);
+        const float* m = rel < num_rel ? weight + (size_t)rel * din * dout : root;
+        float v = 0.f;
+        if (m != nullptr) {
+            if (!transpose) {
+                if (k < din && col < dout) v = m[(size_t)k * dout + col];
+            } else {
+                if (k < dout && col < din) v = m[(size_t)col * dout + k];
+            }
+        }
+        packed[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// producers: gather 16 rows (this wave's share of a 64-row chunk) into a ring slot by LDS-DMA
+// ------------------------------------------------------------------------------------------------
+// W = padded row width (floats).  One global_load_lds_dwordx4 moves 64 lanes x 16 B = RPI rows.
+// idx q0..q3: the wave's 16 row indices (wave-uniform, from scalar loads); idx < 0 -> zeros.
+template <int W, int MODE>
+__device__ __forceinline__ void issue_rows(const float* __restrict__ base, int ld, int n4, int4 q0, int4 q1,
+                                           int4 q2, int4 q3, float* slot_wave_base, int pw, int lane) {
+    constexpr int LPR = W / 4;       // 16-byte lanes per row
+    constexpr int RPI = 64 / LPR;    // rows per DMA instruction
+    constexpr int ROWOPS = 16 / RPI; // DMA instructions per wave and chunk
+    const int rsub = lane / LPR;
+    const int p = lane % LPR;
+#pragma unroll
+    for (int i = 0; i < ROWOPS; ++i) {
+        const int riw = i * RPI + rsub;               // row inside this wave's 16
+        const int idx = pick16(riw, q0, q1, q2, q3);
+        const int row = pw * 16 + riw;                // row inside the chunk
+        const int c = p ^ swizzle<MODE, LPR>(row);    // which 16-B column chunk lands at position p
+        const float* gp = (idx >= 0 && c < n4) ? base + (size_t)idx * ld + c * 4 : g_zero16;
+        dma16(gp, slot_wave_base + i * RPI * W);
+    }
+}
+
+template <int W>
+struct RowOps {
+    static constexpr int value = 16 / (64 / (W / 4));
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward / dX kernel
+// ------------------------------------------------------------------------------------------------
+struct TileArgs {
+    const int* tile_ptr;
+    const int* chunk_rel;
+    const int* chunk_cnt;
+    const int* slot_src;
+    const float* slot_w;
+    const int* slot_dstl;
+    const float* x;
+    const float* wp;
+    const float* bias;
+    float* out;
+    int ldx, din4, dout, ldo, tile, n_owned;
+};
+
+template <int KP, int NP, int NBUF>
+__global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a) {
+    constexpr int KT = KP / 16, NT = NP / 16;
+    constexpr int D = NBUF - 1;                  // chunks the producers run ahead
+    constexpr int ROWOPS = RowOps<KP>::value;
+    constexpr int CW = NT < 4 ? NT : 4;          // consumer waves across output column slices
+    constexpr int RW = 4 / CW;                   // consumer waves across row tiles
+    constexpr int SL = NT < 4 ? 1 : NT / 4;      // column slices per consumer wave
+    constexpr int LPR = KP / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* out_lds = lds;                         // [tile][NP]
+    float* ring = lds + a.tile * NP;              // [NBUF][64][KP]
+    float* wring = ring + NBUF * kChunk * KP;     // [NBUF][64]
+    int* dring = (int*)(wring + NBUF * kChunk);   // [NBUF][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int c0 = ldc(a.tile_ptr, tile);
+    const int nch = ldc(a.tile_ptr, tile + 1) - c0;
+
+    for (int i = tid; i < a.tile * NP; i += kThreads) {
+        const int col = i % NP;
+        out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
+    }
+
+    // ---- producer side -----------------------------------------------------------------------
+    auto issue = [&](int chunk, int buf, int pw) {
+        const long s4 = ((long)chunk * kChunk + pw * 16) >> 2;
+        const int4 q0 = ldc4(a.slot_src, s4), q1 = ldc4(a.slot_src, s4 + 1), q2 = ldc4(a.slot_src, s4 + 2),
+                   q3 = ldc4(a.slot_src, s4 + 3);
+        issue_rows<KP, kRowRead>(a.x, a.ldx, a.din4, q0, q1, q2, q3, ring + (buf * kChunk + pw * 16) * KP, pw, lane);
+        if (pw == 0) dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
+        if (pw == 1) dma4(a.slot_dstl + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
+    };
+    // all but the (D-1) youngest chunks' DMAs of THIS wave have landed
+    auto wait_ahead = [&](int pw) {
+        if (pw < 2) wait_vmcnt<(D - 1) * (ROWOPS + 1)>();
+        else wait_vmcnt<(D - 1) * ROWOPS>();
+    };
+
+    // The two roles run DIFFERENT loops that meet only at s_barrier (a hardware arrival counter: it
+    // does not care which instruction a wave arrives from; both loops execute 1 + nch barriers).
+    // The consumer loop is written FIRST on purpose: hipcc's waitcnt pass is program-order based, so
+    // with no LDS-DMA ahead of it the consumer code gets exact counted waits for its own B-fragment
+    // loads; in a shared loop body every ring read was preceded by s_waitcnt vmcnt(0) ("a DMA may be
+    // pending"), which un-overlapped the B prefetch from the MFMAs.
+    if (wave >= kProducerWaves) {
+        // ---- consumers: ring -> MFMA -> tile accumulator in LDS -----------------------------------
+        const int cwv = wave - kProducerWaves;
+        const int cw = cwv % CW, rw = cwv / CW;
+        const int rowl = lane & 15, kq = lane >> 4;
+        const f32x4* wp4 = (const f32x4*)a.wp;
+        f32x4 bcur[SL][KT], bnext[SL][KT];
+        int rel_cur = ldc(a.chunk_rel, c0);
+#pragma unroll
+        for (int s = 0; s < SL; ++s)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) bcur[s][j] = wp4[((size_t)(rel_cur * NT + cw + CW * s) * KT + j) * 64 + lane];
+        wg_barrier();
+        for (int it = 0; it < nch; ++it) {
+            const int chunk = c0 + it;
+            const int buf = it % NBUF;
+            const int cnt = ldc(a.chunk_cnt, chunk);
+            // prefetch the next chunk's B fragments (L2 resident) under this chunk's MFMAs
+            int rel_next = rel_cur;
+            if (it + 1 < nch) rel_next = ldc(a.chunk_rel, chunk + 1);
+            if (rel_next != rel_cur) {
+#pragma unroll
+                for (int s = 0; s < SL; ++s)
+#pragma unroll
+                    for (int j = 0; j < KT; ++j)
+                        bnext[s][j] = wp4[((size_t)(rel_next * NT + cw + CW * s) * KT + j) * 64 + lane];
+            }
+            const float* hb = ring + buf * kChunk * KP;
+            const int nrt = (cnt + 15) >> 4;
+            for (int rt = rw; rt < nrt; rt += RW) {
+                const int row = rt * 16 + rowl;
+                f32x4 av[KT];
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
+                    av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
+                }
+                const f32x4 w4 = *(const f32x4*)(wring + buf * kChunk + rt * 16 + 4 * kq);
+                const i32x4 d4 = *(const i32x4*)(dring + buf * kChunk + rt * 16 + 4 * kq);
+#pragma unroll
+                for (int s = 0; s < SL; ++s) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], bcur[s][j][0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], bcur[s][j][1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bcur[s][j][2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bcur[s][j][3], acc1, 0, 0, 0);
+                    }
+                    const int col = 16 * (cw + CW * s) + rowl;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // D row (4*kq + i) of this row tile = slot rt*16 + 4*kq + i.  Padding slots were
+                        // gathered as zeros and carry w == 0, dstl == 0: they add an exact +0.
+                        atomicAdd(out_lds + d4[i] * NP + col, (acc0[i] + acc1[i]) * w4[i]);
+                    }
+                }
+            }
+            if (rel_next != rel_cur) {
+#pragma unroll
+                for (int s = 0; s < SL; ++s)
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) bcur[s][j] = bnext[s][j];
+                rel_cur = rel_next;
+            }
+            wg_barrier();
+        }
+        // tell the waitcnt pass that no consumer load is pending when the producer code (next in program
+        // order) reuses these registers; otherwise it waits vmcnt(0) between the prologue DMAs
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    }
+    if (wave < kProducerWaves) {
+        // ---- producers: LDS-DMA gather, D chunks ahead of the consumers -----------------------------
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (k < nch) issue(c0 + k, k % NBUF, wave);
+        if (nch >= D) wait_ahead(wave);
+        else wait_vmcnt<0>();
+        wg_barrier();                       // chunk 0 (and the accumulator init above) visible
+        for (int it = 0; it < nch; ++it) {
+            // slot (it+D)%NBUF held chunk it-1, which the consumers finished before the last barrier
+            if (it + D < nch) {
+                issue(c0 + it + D, (it + D) % NBUF, wave);
+                wait_ahead(wave);           // chunk it+1 has landed
+            } else {
+                wait_vmcnt<0>();
+            }
+            wg_barrier();
+        }
+    }
+
+    // ---- epilogue: the finished tile, whole 16-byte pieces, coalesced ---------------------------
+    const int row0 = tile * a.tile;
+    const int rows = min(a.tile, a.n_owned - row0);
+    const int o4 = (a.dout + 3) >> 2;
+    for (int i = tid; i < rows * o4; i += kThreads) {
+        const int r = i / o4, c4 = i - r * o4;
+        const f32x4 v = *(const f32x4*)(out_lds + r * NP + c4 * 4);
+        *(f32x4*)(a.out + (size_t)(row0 + r) * a.ldo + c4 * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel
+// ------------------------------------------------------------------------------------------------
+struct DwArgs {
+    const int* rel_order;
+    const int* chunk_rel;
+    const int* chunk_cnt;
+    const int* chunk_tile;
+    const int* slot_src;
+    const float* slot_w;
+    const int* slot_dstl;
+    const float* x;
+    const float* g;
+    float* slabs;      // [nblocks + R' + 1][KP*NP]
+    float* bias_slabs; // [nblocks][NP]
+    int ldx, din4, ldg, dout4, tile, n_chunks, num_rel;
+};
+
+__device__ __forceinline__ int4 row_ids(int4 s, int4 d, int base) {
+    return make_int4(s.x < 0 ? -1 : base + d.x, s.y < 0 ? -1 : base + d.y, s.z < 0 ? -1 : base + d.z,
+                     s.w < 0 ? -1 : base + d.w);
+}
+
+template <int KP, int NP, int NBUF>
+__global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
+    constexpr int MT = KP / 16, NT = NP / 16;
+    constexpr int D = NBUF - 1;
+    constexpr int OPS = RowOps<KP>::value + RowOps<NP>::value;
+    constexpr int NSL = NT < 4 ? 1 : NT / 4;              // n-slices per consumer wave
+    constexpr int RWM = NT < 4 ? 4 / NT : 1;              // consumer waves across m-tiles
+    constexpr int MTW = (MT + RWM - 1) / RWM;             // m-tiles per consumer wave
+    constexpr int LPRH = KP / 4, LPRG = NP / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ringh = lds;                                   // [NBUF][64][KP]
+    float* ringg = ringh + NBUF * kChunk * KP;            // [NBUF][64][NP]
+    float* wring = ringg + NBUF * kChunk * NP;            // [NBUF][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int i0 = (int)((long)b * a.n_chunks / nb);
+    const int i1 = (int)((long)(b + 1) * a.n_chunks / nb);
+    const int nch = i1 - i0;
+    if (nch <= 0) return;
+
+    auto issue = [&](int i, int buf, int pw) {
+        const int chunk = ldc(a.rel_order, i);
+        const long s4 = ((long)chunk * kChunk + pw * 16) >> 2;
+        const int4 s0 = ldc4(a.slot_src, s4), s1 = ldc4(a.slot_src, s4 + 1), s2 = ldc4(a.slot_src, s4 + 2),
+                   s3 = ldc4(a.slot_src, s4 + 3);
+        const int base = ldc(a.chunk_tile, chunk) * a.tile;
+        const int4 g0 = row_ids(s0, ldc4(a.slot_dstl, s4), base), g1 = row_ids(s1, ldc4(a.slot_dstl, s4 + 1), base),
+                   g2 = row_ids(s2, ldc4(a.slot_dstl, s4 + 2), base), g3 = row_ids(s3, ldc4(a.slot_dstl, s4 + 3), base);
+        issue_rows<KP, kColRead>(a.x, a.ldx, a.din4, s0, s1, s2, s3, ringh + (buf * kChunk + pw * 16) * KP, pw, lane);
+        issue_rows<NP, kColRead>(a.g, a.ldg, a.dout4, g0, g1, g2, g3, ringg + (buf * kChunk + pw * 16) * NP, pw, lane);
+        if (pw == 0) dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
+    };
+    auto wait_ahead = [&](int pw) {
+        if (pw < 1) wait_vmcnt<(D - 1) * (OPS + 1)>();
+        else wait_vmcnt<(D - 1) * OPS>();
+    };
+
+    const int cwv = wave - kProducerWaves;
+    const int rowl = lane & 15, kq = lane >> 4;
+    const int ntb = NT < 4 ? cwv % NT : cwv;              // first n-slice of this wave (then +4 per s)
+    const int mtb = NT < 4 ? cwv / NT : 0;                // first m-tile (then +RWM per i)
+    f32x4 acc[NSL][MTW];
+    float bsum[NSL];
+    int rel_cur = -1;
+
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            bsum[s] = 0.f;
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto flush = [&]() {
+        float* slab = a.slabs + (size_t)(b + rel_cur) * (KP * NP);
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            const int nt = ntb + 4 * s;
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const int mt = mtb + RWM * i;
+                if (mt < MT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(16 * mt + 4 * kq + r) * NP + 16 * nt + rowl] = acc[s][i][r];
+                }
+            }
+            if (rel_cur == a.num_rel && mtb == 0) {
+                float v = bsum[s];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (kq == 0) a.bias_slabs[(size_t)b * NP + 16 * nt + rowl] = v;
+            }
+        }
+    };
+
+    // separate role loops, consumers first in program order (see rgcn_tile_kernel)
+    if (wave >= kProducerWaves) {
+        zero_acc();
+        wg_barrier();
+        for (int it = 0; it < nch; ++it) {
+            const int chunk = ldc(a.rel_order, i0 + it);
+            const int buf = it % NBUF;
+            const int cnt = ldc(a.chunk_cnt, chunk);
+            const int rel = ldc(a.chunk_rel, chunk);
+            if (rel != rel_cur) {
+                if (rel_cur >= 0) flush();
+                zero_acc();
+                rel_cur = rel;
+            }
+            const bool is_root = rel == a.num_rel;
+            const float* hb = ringh + buf * kChunk * KP;
+            const float* gb = ringg + buf * kChunk * NP;
+            const float* wb = wring + buf * kChunk;
+            const int nks = (cnt + 3) >> 2;
+            for (int ks = 0; ks < nks; ++ks) {
+                const int row = 4 * ks + kq;   // padding rows were DMA'd as zeros: no masking needed
+                const float wv = wb[row];
+                const int swh = swizzle<kColRead, LPRH>(row), swg = swizzle<kColRead, LPRG>(row);
+                float bv[NSL];
+#pragma unroll
+                for (int s = 0; s < NSL; ++s) {
+                    const int col = 16 * (ntb + 4 * s) + rowl;
+                    const float gv = gb[row * NP + (((col >> 2) ^ swg) << 2) + (col & 3)];
+                    if (is_root) bsum[s] += gv;
+                    bv[s] = gv * wv;
+                }
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+                    const int mt = mtb + RWM * i;
+                    if (mt < MT) {
+                        const int col = 16 * mt + rowl;
+                        const float av = hb[row * KP + (((col >> 2) ^ swh) << 2) + (col & 3)];
+#pragma unroll
+                        for (int s = 0; s < NSL; ++s)
+                            acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc[s][i], 0, 0, 0);
+                    }
+                }
+            }
+            wg_barrier();
+        }
+        if (rel_cur >= 0) flush();
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
+    }
+    if (wave < kProducerWaves) {
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (k < nch) issue(i0 + k, k % NBUF, wave);
+        if (nch >= D) wait_ahead(wave);
+        else wait_vmcnt<0>();
+        wg_barrier();
+        for (int it = 0; it < nch; ++it) {
+            if (it + D < nch) {
+                issue(i0 + it + D, (it + D) % NBUF, wave);
+                wait_ahead(wave);
+            } else {
+                wait_vmcnt<0>();
+            }
+            wg_barrier();
+        }
+    }
+}
+
+// slabs -> gradients, fixed summation order (block index ascending) => bitwise reproducible
+__global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
+                                      const int* __restrict__ rel_order, const int* __restrict__ chunk_rel,
+                                      int n_chunks, int nblocks, int num_rel, int KP, int NP, int din, int dout,
+                                      float* __restrict__ d_weight, float* __restrict__ d_root,
+                                      float* __restrict__ d_bias) {
+    const int r = blockIdx.x;
+    if (r == num_rel + 1) {
+        if (d_bias == nullptr) return;
+        for (int n = threadIdx.x; n < dout; n += blockDim.x) {
+            float s = 0.f;
+            for (int b = 0; b < nblocks; ++b) s += bias_slabs[(size_t)b * NP + n];
+            d_bias[n] = s;
+        }
+        return;
+    }
+    float* dst = r < num_rel ? (d_weight ? d_weight + (size_t)r * din * dout : nullptr) : d_root;
+    if (dst == nullptr) return;
+    for (int e = threadIdx.x; e < din * dout; e += blockDim.x) {
+        const int k = e / dout, n = e - k * dout;
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) {
+            const int i0 = (int)((long)b * n_chunks / nblocks);
+            const int i1 = (int)((long)(b + 1) * n_chunks / nblocks);
+            if (i1 <= i0) continue;
+            const int first = chunk_rel[rel_order[i0]], last = chunk_rel[rel_order[i1 - 1]];
+            if (r >= first && r <= last) s += slabs[(size_t)(b + r) * KP * NP + (size_t)k * NP + n];
+        }
+        dst[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: argument checks, LDS sizing, dispatch over the padded widths
+// ------------------------------------------------------------------------------------------------
+constexpr int kDwBlocks = 256;  // one workgroup per CU (LDS-bound occupancy), persistent over its chunk range
+
+template <int KP>
+constexpr int tile_nbuf() { return KP == 128 ? 2 : 4; }
+template <int KP, int NP>
+constexpr int dw_nbuf() { return (KP == 128 || NP == 128) ? 2 : 4; }
+
+static int check_plan(const rgcn_plan_t* p) {
+    if (p == nullptr) return RGCN_ERR_NULL;
+    if (!p->tile_ptr || !p->chunk_rel || !p->chunk_cnt || !p->chunk_tile || !p->rel_order || !p->slot_src ||
+        !p->slot_w || !p->slot_dstl)
+        return RGCN_ERR_NULL;
+    if (p->n_nodes <= 0 || p->n_owned <= 0 || p->num_relations <= 0 || p->tile <= 0 || (p->tile % 16) != 0 ||
+        p->n_tiles <= 0 || p->n_chunks < p->n_tiles || (long)p->n_tiles * p->tile < p->n_owned)
+        return RGCN_ERR_PLAN;
+    return RGCN_OK;
+}
+
+static int check_stride(int ld, int width) {
+    if (width < 1 || width > RGCN_MAX_WIDTH) return RGCN_ERR_WIDTH;
+    if ((ld % 4) != 0 || ld < ((width + 3) / 4) * 4) return RGCN_ERR_STRIDE;
+    return RGCN_OK;
+}
+
+template <int KP, int NP>
+static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
+    constexpr int NBUF = tile_nbuf<KP>();
+    const size_t lds = sizeof(float) * ((size_t)a.tile * NP + (size_t)NBUF * kChunk * (KP + 2));
+    if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
+    auto kern = rgcn_tile_kernel<KP, NP, NBUF>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kThreads), lds, stream, a);
+    return (int)hipGetLastError();
+}
+
+template <int KP>
+static int dispatch_tile_np(int NP, const TileArgs& a, int n_tiles, hipStream_t s) {
+    switch (NP) {
+        case 16: return launch_tile<KP, 16>(a, n_tiles, s);
+        case 32: return launch_tile<KP, 32>(a, n_tiles, s);
+        case 64: return launch_tile<KP, 64>(a, n_tiles, s);
+        case 128: return launch_tile<KP, 128>(a, n_tiles, s);
+    }
+    return RGCN_ERR_WIDTH;
+}
+
+static int dispatch_tile(int KP, int NP, const TileArgs& a, int n_tiles, hipStream_t s) {
+    switch (KP) {
+        case 16: return dispatch_tile_np<16>(NP, a, n_tiles, s);
+        case 32: return dispatch_tile_np<32>(NP, a, n_tiles, s);
+        case 64: return dispatch_tile_np<64>(NP, a, n_tiles, s);
+        case 128: return dispatch_tile_np<128>(NP, a, n_tiles, s);
+    }
+    return RGCN_ERR_WIDTH;
+}
+
+// shared by rgcn_fwd and rgcn_bwd_dx: gather rows of `x` (width kin), scatter into `out` (width nout)
+static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, const float* packed, const float* bias,
+                    float* out, int ldo, int nout, void* stream) {
+    int st = check_plan(plan);
+    if (st != RGCN_OK) return st;
+    if (!x || !packed || !out) return RGCN_ERR_NULL;
+    if ((st = check_stride(ldx, kin)) != RGCN_OK) return st;
+    if ((st = check_stride(ldo, nout)) != RGCN_OK) return st;
+    TileArgs a;
+    a.tile_ptr = plan->tile_ptr;
+    a.chunk_rel = plan->chunk_rel;
+    a.chunk_cnt = plan->chunk_cnt;
+    a.slot_src = plan->slot_src;
+    a.slot_w = plan->slot_w;
+    a.slot_dstl = plan->slot_dstl;
+    a.x = x;
+    a.wp = packed;
+    a.bias = bias;
+    a.out = out;
+    a.ldx = ldx;
+    a.din4 = (kin + 3) / 4;
+    a.dout = nout;
+    a.ldo = ldo;
+    a.tile = plan->tile;
+    a.n_owned = plan->n_owned;
+    return dispatch_tile(padded_width(kin), padded_width(nout), a, plan->n_tiles, (hipStream_t)stream);
+}
+
+template <int KP, int NP>
+static int launch_dw(const DwArgs& a, int nblocks, hipStream_t stream) {
+    constexpr int NBUF = dw_nbuf<KP, NP>();
+    const size_t lds = sizeof(float) * ((size_t)NBUF * kChunk * (KP + NP + 1));
+    if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
+    auto kern = rgcn_dw_kernel<KP, NP, NBUF>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kThreads), lds, stream, a);
+    return (int)hipGetLastError();
+}
+
+template <int KP>
+static int dispatch_dw_np(int NP, const DwArgs& a, int nb, hipStream_t s) {
+    switch (NP) {
+        case 16: return launch_dw<KP, 16>(a, nb, s);
+        case 32: return launch_dw<KP, 32>(a, nb, s);
+        case 64: return launch_dw<KP, 64>(a, nb, s);
+        case 128: return launch_dw<KP, 128>(a, nb, s);
+    }
+    return RGCN_ERR_WIDTH;
+}
+
+static int dispatch_dw(int KP, int NP, const DwArgs& a, int nb, hipStream_t s) {
+    switch (KP) {
+        case 16: return dispatch_dw_np<16>(NP, a, nb, s);
+        case 32: return dispatch_dw_np<32>(NP, a, nb, s);
+        case 64: return dispatch_dw_np<64>(NP, a, nb, s);
+        case 128: return dispatch_dw_np<128>(NP, a, nb, s);
+    }
+    return RGCN_ERR_WIDTH;
+}
+
+static size_t dw_slab_floats(int num_rel, int KP, int NP) { return (size_t)(kDwBlocks + num_rel + 1) * KP * NP; }
+
+}  // namespace rgcn
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+using namespace rgcn;
+
+extern "C" int rgcn_abi_version(void) { return RGCN_ABI_VERSION; }
+
+extern "C" const char* rgcn_status_string(int status) {
+    switch (status) {
+        case RGCN_OK: return "ok";
+        case RGCN_ERR_NULL: return "required pointer is NULL";
+        case RGCN_ERR_WIDTH: return "feature width outside 1..128";
+        case RGCN_ERR_STRIDE: return "row stride must be a multiple of 4 elements and >= the width rounded up to 4";
+        case RGCN_ERR_PLAN: return "inconsistent graph plan";
+        case RGCN_ERR_LDS: return "plan tile too large for the 160 KiB LDS at these widths";
+        case RGCN_ERR_WORKSPACE: return "workspace too small";
+        case RGCN_ERR_DEVICE: return "no gfx950 device";
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown status";
+}
+
+extern "C" int rgcn_padded_width(int width) { return padded_width(width); }
+
+extern "C" size_t rgcn_packed_weight_floats(int num_relations, int din, int dout) {
+    const int a = padded_width(din), b = padded_width(dout);
+    if (a == 0 || b == 0 || num_relations <= 0) return 0;
+    return (size_t)(num_relations + 1) * a * b;
+}
+
+extern "C" int rgcn_pack_weights(const float* weight, const float* root, int num_relations, int din, int dout,
+                                 int transpose, float* packed, void* stream) {
+    if (!weight || !packed) return RGCN_ERR_NULL;
+    if (num_relations <= 0) return RGCN_ERR_PLAN;
+    const int kin = transpose ? dout : din, nout = transpose ? din : dout;
+    const int KP = padded_width(kin), NP = padded_width(nout);
+    if (KP == 0 || NP == 0) return RGCN_ERR_WIDTH;
+    const long total = (long)(num_relations + 1) * KP * NP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rgcn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, root, num_relations,
+                       din, dout, transpose, KP, NP, packed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rgcn_fwd(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* packed_w,
+                        const float* bias, float* out, int ldo, int dout, void* stream) {
+    return run_tile(plan, x, ldx, din, packed_w, bias, out, ldo, dout, stream);
+}
+
+extern "C" int rgcn_bwd_dx(const rgcn_plan_t* plan_t, const float* g, int ldg, int dout, const float* packed_wt,
+                           float* dx, int lddx, int din, void* stream) {
+    return run_tile(plan_t, g, ldg, dout, packed_wt, nullptr, dx, lddx, din, stream);
+}
+
+extern "C" size_t rgcn_bwd_dw_workspace_bytes(const rgcn_plan_t* plan, int din, int dout) {
+    if (plan == nullptr) return 0;
+    const int KP = padded_width(din), NP = padded_width(dout);
+    if (KP == 0 || NP == 0) return 0;
+    return sizeof(float) * (dw_slab_floats(plan->num_relations, KP, NP) + (size_t)kDwBlocks * NP);
+}
+
+extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* g, int ldg,
+                           int dout, void* workspace, size_t workspace_bytes, float* d_weight, float* d_root,
+                           float* d_bias, void* stream) {
+    int st = check_plan(plan);
+    if (st != RGCN_OK) return st;
+    if (!x || !g || !workspace) return RGCN_ERR_NULL;
+    if ((st = check_stride(ldx, din)) != RGCN_OK) return st;
+    if ((st = check_stride(ldg, dout)) != RGCN_OK) return st;
+    const size_t need = rgcn_bwd_dw_workspace_bytes(plan, din, dout);
+    if (workspace_bytes < need) return RGCN_ERR_WORKSPACE;
+    const int KP = padded_width(din), NP = padded_width(dout);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(workspace, 0, need, s);
+    if (e != hipSuccess) return (int)e;
+    DwArgs a;
+    a.rel_order = plan->rel_order;
+    a.chunk_rel = plan->chunk_rel;
+    a.chunk_cnt = plan->chunk_cnt;
+    a.chunk_tile = plan->chunk_tile;
+    a.slot_src = plan->slot_src;
+    a.slot_w = plan->slot_w;
+    a.slot_dstl = plan->slot_dstl;
+    a.x = x;
+    a.g = g;
+    a.slabs = (float*)workspace;
+    a.bias_slabs = a.slabs + dw_slab_floats(plan->num_relations, KP, NP);
+    a.ldx = ldx;
+    a.din4 = (din + 3) / 4;
+    a.ldg = ldg;
+    a.dout4 = (dout + 3) / 4;
+    a.tile = plan->tile;
+    a.n_chunks = plan->n_chunks;
+    a.num_rel = plan->num_relations;
+    st = dispatch_dw(KP, NP, a, kDwBlocks, s);
+    if (st != RGCN_OK) return st;
+    hipLaunchKernelGGL(rgcn_dw_reduce_kernel, dim3(plan->num_relations + 2), dim3(256), 0, s, a.slabs, a.bias_slabs,
+                       plan->rel_order, plan->chunk_rel, plan->n_chunks, kDwBlocks, plan->num_relations, KP, NP, din,
+                       dout, d_weight, d_root, d_bias);
+    return (int)hipGetLastError();
+}

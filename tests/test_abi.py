@@ -1,0 +1,63 @@
+"""The C-ABI shared library loads and exports every symbol include/rgcn_mi355x.h declares, and its
+argument checking rejects bad calls without touching a GPU.  CPU only (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from scaling_rgcn_training_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "rgcn_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgcn_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _declared_symbols()
+    assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+
+
+def test_abi_version_and_sizes():
+    lib = _lib.load()
+    assert lib.rgcn_abi_version() == _lib.ABI_VERSION
+    assert [lib.rgcn_padded_width(w) for w in (1, 16, 17, 63, 64, 65, 128, 129, 0)] == [16, 16, 32, 64, 64, 128, 128, 0, 0]
+    assert lib.rgcn_packed_weight_floats(89, 63, 16) == 90 * 64 * 16
+    assert lib.rgcn_packed_weight_floats(3, 200, 16) == 0
+    assert b"stride" in lib.rgcn_status_string(-3)
+
+
+def test_argument_errors_are_status_codes_not_crashes():
+    lib = _lib.load()
+    ps = _lib.RgcnPlanStruct()  # all zero / NULL
+    assert lib.rgcn_fwd(ctypes.byref(ps), None, 64, 64, None, None, None, 64, 64, None) == -1  # RGCN_ERR_NULL
+    assert lib.rgcn_pack_weights(None, None, 3, 8, 8, 0, None, None) == -1
+    assert lib.rgcn_bwd_dw_workspace_bytes(None, 8, 8) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librgcn_mi355x.so")
+    with pytest.raises(_lib.RgcnLibraryError):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    conv = RGCNConv(8, 4, 3)
+    x = torch.randn(5, 8)
+    ei = torch.tensor([[0, 1], [1, 2]])
+    et = torch.tensor([0, 1])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        conv(x, ei, et)

@@ -1,0 +1,202 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+Needs an MI355X: run with ``pytest -m gpu``.  Tolerance: BASELINE.json's 1e-5 (fp32), atol = rtol."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rgcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    from scaling_rgcn_training_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _abi_layer(dev, ei, et, n, num_rel, x, w_full, root, bias, dout_grad, tile=None, aggr="mean"):
+    """forward, dX, dW through the raw C-ABI wrappers (no autograd)."""
+    from scaling_rgcn_training_amd import _lib, plan as P
+    from scaling_rgcn_training_amd.conv import tile_for, _rows16, _round4
+    din, dout = w_full.shape[1], w_full.shape[2]
+    tile = tile or tile_for(din, dout)
+    plans = P.build_graph_plans(ei.to(dev), et.to(dev), n, num_rel, tile, aggr)
+    xd = _rows16(x.to(dev), din)
+    gd = _rows16(dout_grad.to(dev), dout)
+    wd = w_full.to(dev).contiguous()
+    rd = None if root is None else root.to(dev).contiguous()
+    bd = None if bias is None else bias.to(dev).contiguous()
+    out = torch.full((n, _round4(dout)), float("nan"), device=dev)
+    _lib.fwd(_lib.plan_struct(plans.fwd), xd, din, _lib.pack_weights(wd, rd, False), bd, out, dout)
+    dx = torch.full((n, _round4(din)), float("nan"), device=dev)
+    _lib.bwd_dx(_lib.plan_struct(plans.bwd), gd, dout, _lib.pack_weights(wd, rd, True), dx, din)
+    dw = torch.full((num_rel, din, dout), float("nan"), device=dev)
+    dr = torch.full((din, dout), float("nan"), device=dev)
+    db = torch.full((dout,), float("nan"), device=dev)
+    _lib.bwd_dw(_lib.plan_struct(plans.fwd), xd, din, gd, dout, dw, dr, db)
+    torch.cuda.synchronize()
+    return (out[:, :dout].cpu().numpy(), dx[:, :din].cpu().numpy(), dw.cpu().numpy(), dr.cpu().numpy(),
+            db.cpu().numpy())
+
+
+def test_abi_matches_golden(dev, golden):
+    if str(golden["mode"]) != "full":
+        pytest.skip("weight modes are covered at module level")
+    g = golden
+    f = lambda k: torch.from_numpy(g[k])
+    out, dx, dw, dr, db = _abi_layer(dev, f("edge_index").long(), f("edge_type").long(), int(g["num_nodes"]),
+                                     int(g["num_relations"]), f("x"), f("weight"), f("root"), f("bias"), f("dout"))
+    np.testing.assert_allclose(out, g["out"], **TOL)
+    np.testing.assert_allclose(dx, g["d_x"], **TOL)
+    np.testing.assert_allclose(dw, g["d_wfull"], **TOL)
+    np.testing.assert_allclose(dr, g["d_root"], **TOL)
+    np.testing.assert_allclose(db, g["d_bias"], **TOL)
+
+
+def _module_from_golden(dev, g):
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    mode = str(g["mode"])
+    din, dout = g["x"].shape[1], g["out"].shape[1]
+    kw = {}
+    if mode == "basis":
+        kw["num_bases"] = g["weight"].shape[0]
+    if mode == "block":
+        kw["num_blocks"] = int(g["nb"])
+    conv = RGCNConv(din, dout, int(g["num_relations"]), **kw).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(g["weight"]))
+        conv.root.copy_(torch.from_numpy(g["root"]))
+        conv.bias.copy_(torch.from_numpy(g["bias"]))
+        if mode == "basis":
+            conv.comp.copy_(torch.from_numpy(g["comp"]))
+    return conv
+
+
+def test_module_autograd_matches_golden(dev, golden):
+    g = golden
+    conv = _module_from_golden(dev, g)
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    ei = torch.from_numpy(g["edge_index"]).long().to(dev)
+    et = torch.from_numpy(g["edge_type"]).long().to(dev)
+    out = conv(x, ei, et)
+    out.backward(torch.from_numpy(g["dout"]).to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], **TOL)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["d_x"], **TOL)
+    np.testing.assert_allclose(conv.root.grad.cpu().numpy(), g["d_root"], **TOL)
+    np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), g["d_bias"], **TOL)
+    mode = str(g["mode"])
+    if mode == "full":
+        np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), g["d_wfull"], **TOL)
+    else:  # chain rule of the oracle's effective weight, fp64
+        w = torch.from_numpy(g["weight"]).double().requires_grad_(True)
+        comp = torch.from_numpy(g["comp"]).double().requires_grad_(True) if mode == "basis" else None
+        wf = O.effective_weight(w, comp, int(g["num_relations"]), int(g["nb"]) if mode == "block" else None,
+                                g["x"].shape[1], g["out"].shape[1])
+        wf.backward(torch.from_numpy(g["d_wfull"]))
+        np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), w.grad.numpy(), **TOL)
+        if comp is not None:
+            np.testing.assert_allclose(conv.comp.grad.cpu().numpy(), comp.grad.numpy(), **TOL)
+
+
+WIDTHS = [(64, 64), (63, 16), (16, 5), (16, 16), (32, 64), (64, 32), (48, 100), (128, 128), (128, 16), (7, 128),
+          (1, 1), (100, 36)]
+
+
+@pytest.mark.parametrize("din,dout", WIDTHS)
+def test_random_graph_all_width_classes(dev, din, dout):
+    n, e, r = 1500, 20000, 9
+    ei, et = O.synthetic_graph(n, e, r, seed=din * 131 + dout)
+    et = et.clamp(max=r - 2)  # last relation empty (the reference's dead 2R slot)
+    ei[:, 10] = ei[:, 9]      # duplicate edge
+    ei[1, 11] = ei[0, 11]     # self loop
+    w, root, bias = O.synthetic_params(r, din, dout, seed=3)
+    g = torch.Generator().manual_seed(11)
+    bias = torch.randn(dout, generator=g) * 0.1
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    out, dx, dw, dr, db = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg)
+    np.testing.assert_allclose(out, ref, **TOL)
+    np.testing.assert_allclose(dx, gr["x"], **TOL)
+    np.testing.assert_allclose(dw, gr["weight"], rtol=1e-5, atol=3e-5)  # sums over ~2k edges per relation
+    np.testing.assert_allclose(dr, gr["root"], rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(db, gr["bias"], rtol=1e-5, atol=3e-5)
+    assert np.all(dw[r - 1] == 0.0)
+
+
+def test_skewed_hub_graph_and_sum_aggr(dev):
+    n, e, r, din, dout = 4000, 60000, 5, 64, 64
+    ei, et = O.synthetic_graph(n, e, r, seed=5, skew=True)
+    w, root, bias = O.synthetic_params(r, din, dout, seed=4)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    for aggr in ("mean", "sum"):
+        ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(),
+                                       dg.numpy(), aggr=aggr)
+        out, dx, dw, dr, db = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, aggr=aggr)
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(dx, gr["x"], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gr["x"]).max())))
+        np.testing.assert_allclose(dw, gr["weight"], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(gr["weight"]).max())))
+
+
+def test_empty_graph_and_tiny_tiles(dev):
+    n, r, din, dout = 37, 3, 12, 20
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    et = torch.zeros(0, dtype=torch.long)
+    w, root, bias = O.synthetic_params(r, din, dout, seed=1)
+    bias = bias + 0.5
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    out, dx, dw, dr, db = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=16)
+    np.testing.assert_allclose(out, (x @ root + bias).numpy(), **TOL)
+    np.testing.assert_allclose(dx, (dg @ root.T).numpy(), **TOL)
+    assert np.all(dw == 0)
+    np.testing.assert_allclose(dr, (x.T @ dg).numpy(), rtol=1e-5, atol=3e-5)
+    np.testing.assert_allclose(db, dg.sum(0).numpy(), rtol=1e-5, atol=3e-5)
+
+
+def test_run_to_run_bitwise_determinism(dev):
+    n, e, r = 3000, 50000, 6
+    ei, et = O.synthetic_graph(n, e, r, seed=9)
+    w, root, bias = O.synthetic_params(r, 64, 64, seed=9)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, 64, generator=g)
+    dg = torch.randn(n, 64, generator=g)
+    a = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg)
+    b = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
+def test_frozen_params_and_override_contract(dev):
+    """override_params re-binds fresh (possibly frozen) Parameters (model/layers.py:33-46)."""
+    from scaling_rgcn_training_amd.layers import Emb_Layers
+    from scaling_rgcn_training_amd.data import Data
+    torch.manual_seed(0)
+    n, r = 200, 5
+    ei, et = O.synthetic_graph(n, 1500, r, seed=1)
+    data = Data(edge_index=ei)
+    data.edge_type = et
+    data = data.to(dev)
+    m = Emb_Layers(r, 16, 4, n, 63, None).to(dev)
+    src = Emb_Layers(r, 16, 4, n, 63, None).to(dev)
+    m.override_params(src.rgcn1.weight.clone(), src.rgcn1.bias.clone(), src.rgcn1.root.clone(),
+                      src.rgcn2.weight.clone(), src.rgcn2.bias.clone(), src.rgcn2.root.clone(), grad=False)
+    out = m(data, torch.sigmoid)
+    out.sum().backward()
+    assert m.rgcn1.weight.grad is None and m.rgcn2.root.grad is None and m.rgcn1.bias.grad is None
+    assert m.embedding.weight.grad is not None and torch.isfinite(m.embedding.weight.grad).all()
+    # forward equals the oracle evaluated with the transferred parameters
+    with torch.no_grad():
+        h = O.rgcn_conv_loop(m.embedding.weight.cpu().double(), ei, et, src.rgcn1.weight.cpu().double(),
+                             src.rgcn1.root.cpu().double(), src.rgcn1.bias.cpu().double()).relu()
+        ref = torch.sigmoid(O.rgcn_conv_loop(h, ei, et, src.rgcn2.weight.cpu().double(),
+                                             src.rgcn2.root.cpu().double(), src.rgcn2.bias.cpu().double()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), **TOL)
