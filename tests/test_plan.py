@@ -15,6 +15,11 @@ def _plans_from_golden(g, tile):
     return P.build_graph_plans(ei, et, int(g["num_nodes"]), int(g["num_relations"]), tile)
 
 
+def _distinct(ei, et, n, r):
+    ei, et = torch.as_tensor(ei).long(), torch.as_tensor(et).long()
+    return int(torch.unique((ei[0] * n + ei[1]) * r + et).numel())
+
+
 def _check_invariants(plan, n_real_edges):
     c = P.CHUNK
     assert plan.slot_src.numel() == plan.n_chunks * c
@@ -43,7 +48,7 @@ def test_plan_walk_matches_golden(golden, tile):
     if tile == 4 and golden["edge_index"].shape[1] > 2000:
         pytest.skip("tiny tiles only on small graphs")
     plans = _plans_from_golden(golden, tile)
-    e = golden["edge_index"].shape[1]
+    e = _distinct(golden["edge_index"], golden["edge_type"], int(golden["num_nodes"]), int(golden["num_relations"]))
     _check_invariants(plans.fwd, e)
     _check_invariants(plans.bwd, e)
     w_all = np.concatenate([golden["weight"], golden["root"][None]], 0).astype(np.float64)
@@ -78,20 +83,33 @@ def test_empty_graph_and_isolated_nodes():
 
 
 def test_hub_spans_many_chunks():
-    n, e = 50, 1000
+    n, e = 500, 1000
     g = torch.Generator().manual_seed(0)
     src = torch.randint(0, n, (e,), generator=g)
     dst = torch.full((e,), 7)
     typ = torch.randint(0, 2, (e,), generator=g)
     ei = torch.stack([src, dst])
     plans = P.build_graph_plans(ei, typ, n, 3, 16)
-    _check_invariants(plans.fwd, e)
-    assert plans.fwd.n_chunks > e // P.CHUNK
+    _check_invariants(plans.fwd, _distinct(ei, typ, n, 3))
+    assert plans.fwd.n_edges == e
     w, root, bias = O.synthetic_params(3, 6, 4)
     x = torch.randn(n, 6, generator=g)
     ref = O.rgcn_conv_dense(x.numpy(), ei.numpy(), typ.numpy(), w.numpy(), root.numpy(), bias.numpy())
     w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0)
     np.testing.assert_allclose(emulate_spmm(plans.fwd, x.numpy(), w_all, bias.numpy()), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_duplicate_triples_merge_into_one_weighted_slot():
+    # 3 copies of 0->2 (rel 0) and one 1->2 (rel 0): c[2,0] = 4, merged weights 3/4 and 1/4
+    ei = torch.tensor([[0, 0, 1, 0], [2, 2, 2, 2]])
+    et = torch.tensor([0, 0, 0, 0])
+    p = P.build_graph_plans(ei, et, 3, 1, 16).fwd
+    valid = p.slot_src >= 0
+    rel = torch.repeat_interleave(p.chunk_rel, P.CHUNK)
+    real = valid & (rel == 0)
+    assert real.sum() == 2
+    assert sorted(zip(p.slot_src[real].tolist(), p.slot_w[real].tolist())) == [(0, 0.75), (1, 0.25)]
+    assert torch.all(p.slot_dstl[real] == 2)
 
 
 def test_out_of_range_inputs_raise():
