@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- edges/s per R-GCN layer (forward + backward) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nodes .. --edges .. --relations .. --width ..]
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on; fits one GPU):
+synthetic graph, 10M nodes / 100M edges / 32 relations, features 64 -> 64, fp32, inputs of
+SURVEY.md 8d (uniform src/dst/type, x ~ N(0,1), dOut ~ N(0,1)), generated on the device.
+
+A "step" is ONE pass of the hot path over the whole graph: RGCNConv.forward (weight pack + tile
+kernel) and its autograd backward (W^T pack + dX tile kernel on the transposed plan + dW kernel +
+slab reduction), called through the drop-in nn.Module exactly as reference model/layers.py does.
+The graph plan (sort / chunk layout) is built once before the timed region and reported separately
+(plan_build_s), as SURVEY.md 8d prescribes.  Inputs are resident in HBM when the clock starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the SAME graph is
+edge-partitioned by destination range (strong scaling); every step includes the per-layer
+all-gathers and the weight-gradient all-reduce.  value = E * K / max-over-ranks time.
+
+The JSON line also carries `roofline` for the dominant kernel (HIP-event timed per launch; algorithmic
+bytes of SURVEY.md 8d / DESIGN.md) and `cpu_baseline`: the oracle's PyG-loop restatement timed on this
+host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(e, n, r, din, dout):
+    """SURVEY.md 8d, per launch.  int32 index + fp32 weight per edge, fp32 features."""
+    w = 4 * (r + 1) * din * dout
+    fwd = e * (8 + 4 * din) + n * (4 + 4 * din + 4 * dout) + w
+    dx = e * (8 + 4 * dout) + n * (4 + 4 * dout + 4 * din) + w
+    dw = e * (8 + 4 * din) + n * (4 + 4 * din) + w          # dOut counted once, in dx
+    return {"fwd": fwd, "dx": dx, "dw": dw}
+
+
+def synthetic_on_device(n, e, r, din, dout, dev, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    src = torch.randint(0, n, (e,), generator=g, device=dev)
+    dst = torch.randint(0, n, (e,), generator=g, device=dev)
+    typ = torch.randint(0, r, (e,), generator=g, device=dev)
+    x = torch.randn(n, din, generator=g, device=dev)
+    dout_grad = torch.randn(n, dout, generator=g, device=dev)
+    bw, br = math.sqrt(6.0 / (din * dout)), math.sqrt(6.0 / (din + dout))
+    weight = torch.empty(r, din, dout, device=dev).uniform_(-bw, bw, generator=g)
+    root = torch.empty(din, dout, device=dev).uniform_(-br, br, generator=g)
+    return torch.stack([src, dst]), typ, x, dout_grad, weight, root
+
+
+def cpu_baseline(r, din, dout, n=200_000, e=2_000_000, reps=2):
+    """The oracle's restatement of the PyG loop (the ops the reference executes on CPU), fwd + bwd."""
+    from oracle import rgcn_oracle as O
+    # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole host and
+    # oversubscribing ATen's OpenMP pool makes the loop crawl)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
+    torch.set_num_threads(threads)
+    ei, et = O.synthetic_graph(n, e, r, seed=0)
+    w, root, bias = O.synthetic_params(r, din, dout, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, din, generator=g).requires_grad_(True)
+    dg = torch.randn(n, dout, generator=g)
+    for t in (w, root, bias):
+        t.requires_grad_(True)
+    best = float("inf")
+    for i in range(reps + 1):
+        for t in (x, w, root, bias):
+            t.grad = None
+        t0 = time.perf_counter()
+        out = O.rgcn_conv_loop(x, ei, et, w, root, bias)
+        out.backward(dg)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            best = min(best, dt)
+    return {"value": e / best, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"synthetic {n} nodes / {e} edges / {r} relations, {din}->{dout}, fwd+bwd, best of {reps} "
+                      f"(PyG-loop restatement oracle/rgcn_oracle.py under autograd, torch {torch.__version__} CPU)"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--edges", type=int, default=100_000_000)
+    ap.add_argument("--relations", type=int, default=32)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import __graft_entry__ as ge
+    ge.build()
+    from scaling_rgcn_training_amd import _lib, dist as rdist
+    from scaling_rgcn_training_amd.conv import RGCNConv
+
+    n, e, r, d = args.nodes, args.edges, args.relations, args.width
+    log(f"rank {rank}/{world}: generating {n} nodes / {e} edges / {r} relations on {torch.cuda.get_device_name(dev)}")
+    ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, d, d, dev)
+    conv = RGCNConv(d, d, r).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(weight)
+        conv.root.copy_(root)
+    del weight, root
+    if world > 1:
+        rdist.attach(conv, n)
+    x.requires_grad_(True)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plans = conv._plans(x, ei, et)          # one-time graph plan (excluded from the metric)
+    torch.cuda.synchronize()
+    plan_s = time.perf_counter() - t0
+    log(f"plan built in {plan_s:.2f}s: fwd {plans.fwd.n_chunks} chunks / {plans.fwd.n_tiles} tiles, "
+        f"bwd {plans.bwd.n_chunks} chunks, {(plans.fwd.nbytes() + plans.bwd.nbytes()) / 1e9:.2f} GB")
+
+    def step():
+        x.grad = None
+        conv.weight.grad = conv.root.grad = conv.bias.grad = None
+        out = conv(x, ei, et)
+        out.backward(dg)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    log(f"{args.steps} timed steps: {dt / args.steps * 1e3:.2f} ms/step")
+
+    # ---- per-launch timing of the three hot kernels (HIP events on the launch stream) --------------
+    fp, bp = plans.fwd, plans.bwd
+    xd = x.detach()
+    wf, rt, bs = conv.weight.detach(), conv.root.detach(), conv.bias.detach()
+    out = torch.empty(max(fp.n_owned, 1), d, device=dev)
+    dxb = torch.empty(max(bp.n_owned, 1), d, device=dev)
+    dw, dr, db = torch.empty_like(wf), torch.empty_like(rt), torch.empty_like(bs)
+    pk, pkt = _lib.pack_weights(wf, rt, False), _lib.pack_weights(wf, rt, True)
+    psf, psb = _lib.plan_struct(fp), _lib.plan_struct(bp)
+    g_own = dg[fp.node_begin:fp.node_end]
+    launches = {
+        "fwd": lambda: _lib.fwd(psf, xd, d, pk, bs, out, d),
+        "dx": lambda: _lib.bwd_dx(psb, dg, d, pkt, dxb, d),
+        "dw": lambda: _lib.bwd_dw(psf, xd, d, g_own, d, dw, dr, db),
+    }
+    kernel_ms = {}
+    reps = max(3, min(args.steps, 10))
+    for name, fn in launches.items():
+        fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        kernel_ms[name] = sum(a.elapsed_time(b) for a, b in evs) / reps
+        log(f"launch {name}: {kernel_ms[name]:.3f} ms")
+    # the forward and dX launches run the same kernel (rgcn_tile_kernel<64,64,4>); dw adds a memset + reduce
+    alg = algorithmic_bytes(e / world, n / world, r, d, d)
+    tile_ms = kernel_ms["fwd"] + kernel_ms["dx"]
+    if tile_ms >= kernel_ms["dw"]:
+        kname, kbytes, kms = "rgcn_tile_kernel<64,64,4> (fwd + dX launches)", (alg["fwd"] + alg["dx"]) / 2, tile_ms / 2
+    else:
+        kname, kbytes, kms = "rgcn_dw_kernel<64,64,4>", alg["dw"], kernel_ms["dw"]
+    achieved = kbytes / (kms * 1e-3) / 1e9
+
+    if rank == 0:
+        rec = {
+            "metric": "edges/s per RGCN layer (fwd+bwd)",
+            "value": e * args.steps / dt,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {n} nodes / {e} edges / {r} relations, {d}->{d} fp32, "
+                                   f"full-graph layer fwd+bwd (BASELINE.json configs[3])",
+                       "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
+                       "partition": f"dst-range x{world}" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms},
+            "kernel_ms": kernel_ms,
+            "plan_build_s": plan_s,
+            "plan_bytes": fp.nbytes() + bp.nbytes(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU baseline sample")
+            rec["cpu_baseline"] = cpu_baseline(r, d, d)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

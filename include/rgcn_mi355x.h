@@ -66,7 +66,7 @@ typedef struct rgcn_plan {
     const int32_t* rel_order;  /* [n_chunks] chunk ids sorted by (relation, tile) */
     const int32_t* slot_src;   /* [n_chunks * 64] row to gather, -1 = padding */
     const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */
-    const int32_t* slot_dstl;  /* [n_chunks * 64] row inside the tile */
+    const int32_t* slot_dstl;  /* [n_chunks * 64] row inside the tile, ascending inside a chunk; padding = tile */
 } rgcn_plan_t;
 
 int rgcn_abi_version(void);

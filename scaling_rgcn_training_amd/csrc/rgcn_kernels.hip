@@ -11,6 +11,7 @@
 //   rgcn_dw_kernel        weight gradients: per relation, dB_rel += (w_e x[src_e])^T g[dst_e]
 //                         (relation-major walk; register accumulators; one partial slab per (workgroup, rel))
 //   rgcn_dw_reduce_kernel fixed-order sum of the slabs -> d_weight / d_root / d_bias
+#include <cstdlib>
 #include "rgcn_common.h"
 #include "../../include/rgcn_mi355x.h"
 
@@ -53,33 +54,32 @@ __global__ void rgcn_pack_kernel(const float* __restrict__ weight, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// producers: gather 16 rows (this wave's share of a 64-row chunk) into a ring slot by LDS-DMA
+// producers: gather the 64 rows of a chunk into a ring slot by LDS-DMA -- ONE wave per chunk
 // ------------------------------------------------------------------------------------------------
+// Chunk k of a workgroup's sequence belongs to producer wave k % 4, so a wave issues every 4th
+// iteration.  That cadence hides the latency of the chunk's row-index load (one coalesced 256-B
+// vector load per chunk, issued right after the previous chunk's DMAs and first used 4 iterations
+// later); a scalar index load issued in the same iteration as its DMAs was a demand miss to HBM
+// per chunk and capped the first version at ~5 us per chunk.
 // W = padded row width (floats).  One global_load_lds_dwordx4 moves 64 lanes x 16 B = RPI rows.
-// idx q0..q3: the wave's 16 row indices (wave-uniform, from scalar loads); idx < 0 -> zeros.
+// idxv: lane l holds the index of chunk row l (< 0 -> the row is zeros).
 template <int W, int MODE>
-__device__ __forceinline__ void issue_rows(const float* __restrict__ base, int ld, int n4, int4 q0, int4 q1,
-                                           int4 q2, int4 q3, float* slot_wave_base, int pw, int lane) {
+__device__ __forceinline__ void issue_rows(const float* __restrict__ base, int ld, int n4, int idxv,
+                                           float* slot_base, int lane) {
     constexpr int LPR = W / 4;       // 16-byte lanes per row
     constexpr int RPI = 64 / LPR;    // rows per DMA instruction
-    constexpr int ROWOPS = 16 / RPI; // DMA instructions per wave and chunk
+    constexpr int NOPS = 64 / RPI;   // DMA instructions per chunk
     const int rsub = lane / LPR;
     const int p = lane % LPR;
 #pragma unroll
-    for (int i = 0; i < ROWOPS; ++i) {
-        const int riw = i * RPI + rsub;               // row inside this wave's 16
-        const int idx = pick16(riw, q0, q1, q2, q3);
-        const int row = pw * 16 + riw;                // row inside the chunk
+    for (int i = 0; i < NOPS; ++i) {
+        const int row = i * RPI + rsub;               // row inside the chunk
+        const int idx = __shfl(idxv, row);
         const int c = p ^ swizzle<MODE, LPR>(row);    // which 16-B column chunk lands at position p
         const float* gp = (idx >= 0 && c < n4) ? base + (size_t)idx * ld + c * 4 : g_zero16;
-        dma16(gp, slot_wave_base + i * RPI * W);
+        dma16(gp, slot_base + i * RPI * W);
     }
 }
-
-template <int W>
-struct RowOps {
-    static constexpr int value = 16 / (64 / (W / 4));
-};
 
 // ------------------------------------------------------------------------------------------------
 // forward / dX kernel
@@ -96,21 +96,21 @@ struct TileArgs {
     const float* bias;
     float* out;
     int ldx, din4, dout, ldo, tile, n_owned;
+    int dbg;  // diagnostic ablations (RGCN_DEBUG_MODE env): 1 skip MFMA+accumulate, 2 skip DMA, 4 skip B loads
 };
 
 template <int KP, int NP, int NBUF>
 __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a) {
     constexpr int KT = KP / 16, NT = NP / 16;
     constexpr int D = NBUF - 1;                  // chunks the producers run ahead
-    constexpr int ROWOPS = RowOps<KP>::value;
-    constexpr int CW = NT < 4 ? NT : 4;          // consumer waves across output column slices
-    constexpr int RW = 4 / CW;                   // consumer waves across row tiles
+    static_assert(D >= 1 && D <= kProducerWaves, "one chunk in flight per producer wave");
+    constexpr int CW = NT < 4 ? NT : 4;          // consumer waves that own output column slices
     constexpr int SL = NT < 4 ? 1 : NT / 4;      // column slices per consumer wave
     constexpr int LPR = KP / 4;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* out_lds = lds;                         // [tile][NP]
-    float* ring = lds + a.tile * NP;              // [NBUF][64][KP]
+    float* ring = lds + (a.tile + 1) * NP;        // [NBUF][64][KP]  (row `tile` of out_lds: dummy)
     float* wring = ring + NBUF * kChunk * KP;     // [NBUF][64]
     int* dring = (int*)(wring + NBUF * kChunk);   // [NBUF][64]
 
@@ -121,25 +121,10 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
     const int c0 = ldc(a.tile_ptr, tile);
     const int nch = ldc(a.tile_ptr, tile + 1) - c0;
 
-    for (int i = tid; i < a.tile * NP; i += kThreads) {
+    for (int i = tid; i < (a.tile + 1) * NP; i += kThreads) {
         const int col = i % NP;
         out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
     }
-
-    // ---- producer side -----------------------------------------------------------------------
-    auto issue = [&](int chunk, int buf, int pw) {
-        const long s4 = ((long)chunk * kChunk + pw * 16) >> 2;
-        const int4 q0 = ldc4(a.slot_src, s4), q1 = ldc4(a.slot_src, s4 + 1), q2 = ldc4(a.slot_src, s4 + 2),
-                   q3 = ldc4(a.slot_src, s4 + 3);
-        issue_rows<KP, kRowRead>(a.x, a.ldx, a.din4, q0, q1, q2, q3, ring + (buf * kChunk + pw * 16) * KP, pw, lane);
-        if (pw == 0) dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
-        if (pw == 1) dma4(a.slot_dstl + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
-    };
-    // all but the (D-1) youngest chunks' DMAs of THIS wave have landed
-    auto wait_ahead = [&](int pw) {
-        if (pw < 2) wait_vmcnt<(D - 1) * (ROWOPS + 1)>();
-        else wait_vmcnt<(D - 1) * ROWOPS>();
-    };
 
     // The two roles run DIFFERENT loops that meet only at s_barrier (a hardware arrival counter: it
     // does not care which instruction a wave arrives from; both loops execute 1 + nch barriers).
@@ -149,16 +134,26 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
     // pending"), which un-overlapped the B prefetch from the MFMAs.
     if (wave >= kProducerWaves) {
         // ---- consumers: ring -> MFMA -> tile accumulator in LDS -----------------------------------
+        // Consumer wave cw owns output column slices {cw + CW*s}; with fewer than 4 slices (NP < 64) the
+        // surplus consumer waves only keep the barrier count (same time per row: the MFMA work per row
+        // shrinks with NP).  Exclusive column ownership + the run-sum below make every accumulator
+        // update a plain LDS read-modify-write: no LDS float atomics (ds_add_f32 retires ~1 lane per 3
+        // cycles on gfx950, ~190 cycles per wave-instruction: tools/probes/lds_atomic_rate.hip; it
+        // was 60 % of the first version's kernel time) and bit-reproducible sums.
         const int cwv = wave - kProducerWaves;
-        const int cw = cwv % CW, rw = cwv / CW;
+        const bool active = cwv < CW;
+        const int cw = cwv;
         const int rowl = lane & 15, kq = lane >> 4;
         const f32x4* wp4 = (const f32x4*)a.wp;
         f32x4 bcur[SL][KT], bnext[SL][KT];
         int rel_cur = ldc(a.chunk_rel, c0);
+        if (active) {
 #pragma unroll
-        for (int s = 0; s < SL; ++s)
+            for (int s = 0; s < SL; ++s)
 #pragma unroll
-            for (int j = 0; j < KT; ++j) bcur[s][j] = wp4[((size_t)(rel_cur * NT + cw + CW * s) * KT + j) * 64 + lane];
+                for (int j = 0; j < KT; ++j)
+                    bcur[s][j] = wp4[((size_t)(rel_cur * NT + cw + CW * s) * KT + j) * 64 + lane];
+        }
         wg_barrier();
         for (int it = 0; it < nch; ++it) {
             const int chunk = c0 + it;
@@ -167,7 +162,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             // prefetch the next chunk's B fragments (L2 resident) under this chunk's MFMAs
             int rel_next = rel_cur;
             if (it + 1 < nch) rel_next = ldc(a.chunk_rel, chunk + 1);
-            if (rel_next != rel_cur) {
+            const bool swap_b = active && rel_next != rel_cur && !(a.dbg & 4);
+            if (swap_b) {
 #pragma unroll
                 for (int s = 0; s < SL; ++s)
 #pragma unroll
@@ -175,8 +171,10 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                         bnext[s][j] = wp4[((size_t)(rel_next * NT + cw + CW * s) * KT + j) * 64 + lane];
             }
             const float* hb = ring + buf * kChunk * KP;
-            const int nrt = (cnt + 15) >> 4;
-            for (int rt = rw; rt < nrt; rt += RW) {
+            const float* wb = wring + buf * kChunk;
+            const int* db = dring + buf * kChunk;
+            const int nrt = (!active || (a.dbg & 1)) ? 0 : (cnt + 15) >> 4;
+            for (int rt = 0; rt < nrt; ++rt) {
                 const int row = rt * 16 + rowl;
                 f32x4 av[KT];
 #pragma unroll
@@ -184,8 +182,24 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                     const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
                     av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
                 }
-                const f32x4 w4 = *(const f32x4*)(wring + buf * kChunk + rt * 16 + 4 * kq);
-                const i32x4 d4 = *(const i32x4*)(dring + buf * kChunk + rt * 16 + 4 * kq);
+                // rows of a chunk are sorted by destination, so equal destinations are adjacent runs.
+                // d4/w4: rows 4*kq + i (the rows whose MFMA results this lane holds); dm/dm1: row rowl
+                // and its successor; d5: the row after this lane's four.  A run ends at a change of
+                // destination or at the end of the row tile (the next tile is processed after this one).
+                const f32x4 w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
+                const i32x4 d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
+                const int dm = db[rt * 16 + rowl];
+                const int dm1 = rowl < 15 ? db[rt * 16 + rowl + 1] : -2;
+                const int d5 = kq < 3 ? db[rt * 16 + 4 * kq + 4] : -2;
+                const bool last_m = dm != dm1;
+                // P[m][k] = w_k if row k belongs to the run that ENDS at row m, else 0.  Z = P . Y puts each
+                // run's weighted sum on its last row and zeros elsewhere, so the rows that write below
+                // have pairwise distinct destinations inside this tile.  Y's accumulator registers are
+                // already in B-operand layout for MFMA step i with k = 4*k' + i: no data movement.
+                float pm[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pm[i] = (last_m && d4[i] == dm) ? w4[i] : 0.f;
+                const bool live[4] = {d4[0] != d4[1], d4[1] != d4[2], d4[2] != d4[3], d4[3] != d5};
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -196,22 +210,33 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bcur[s][j][2], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bcur[s][j][3], acc1, 0, 0, 0);
                     }
+                    const f32x4 y = acc0 + acc1;
+                    f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], y[0], z0, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], y[1], z1, 0, 0, 0);
+                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], y[2], z0, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], y[3], z1, 0, 0, 0);
+                    const f32x4 z = z0 + z1;
                     const int col = 16 * (cw + CW * s) + rowl;
+                    // rows that do not end a run (and padding, destination == tile) go to the dummy row
+                    float* dst[4];
+                    float old[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        // D row (4*kq + i) of this row tile = slot rt*16 + 4*kq + i.  Padding slots were
-                        // gathered as zeros and carry w == 0, dstl == 0: they add an exact +0.
-                        atomicAdd(out_lds + d4[i] * NP + col, (acc0[i] + acc1[i]) * w4[i]);
+                        dst[i] = out_lds + (live[i] ? d4[i] : a.tile) * NP + col;
+                        old[i] = *dst[i];
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *dst[i] = old[i] + z[i];
                 }
             }
-            if (rel_next != rel_cur) {
+            if (swap_b) {
 #pragma unroll
                 for (int s = 0; s < SL; ++s)
 #pragma unroll
                     for (int j = 0; j < KT; ++j) bcur[s][j] = bnext[s][j];
-                rel_cur = rel_next;
             }
+            rel_cur = rel_next;
             wg_barrier();
         }
         // tell the waitcnt pass that no consumer load is pending when the producer code (next in program
@@ -219,23 +244,44 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     if (wave < kProducerWaves) {
-        // ---- producers: LDS-DMA gather, D chunks ahead of the consumers -----------------------------
+        // ---- producers: LDS-DMA gather, D chunks ahead of the consumers; wave (k % 4) owns chunk k ----
+        const int pw = wave;
+        int knext = pw;                                   // this wave's next chunk
+        // Row indices of this wave's NEXT chunk: one coalesced load, issued right after the current
+        // chunk's DMAs and not touched until the wave's next turn 4 iterations later (any use here would
+        // make hipcc wait vmcnt(0) on the spot, i.e. for the DMAs just issued).  The address is clamped
+        // so the load is always valid; issue() only runs for k < nch.
+        auto load_idx = [&](int k) {
+            const int kk = k < nch ? k : nch - 1;
+            return a.slot_src[(size_t)(c0 + kk) * kChunk + lane];
+        };
+        int idxv = load_idx(knext);
+        auto issue = [&](int k) {                         // k == knext
+            const int chunk = c0 + k, buf = k % NBUF;
+            if (!(a.dbg & 2))
+                issue_rows<KP, kRowRead>(a.x, a.ldx, a.din4, idxv, ring + buf * kChunk * KP, lane);
+            else
+                issue_rows<KP, kRowRead>(a.x, a.ldx, 0, idxv, ring + buf * kChunk * KP, lane);  // all lanes -> zeros
+            dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
+            dma4(a.slot_dstl + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
+            knext += kProducerWaves;
+            idxv = load_idx(knext);                       // youngest op of this wave from here on
+        };
 #pragma unroll
         for (int k = 0; k < D; ++k)
-            if (k < nch) issue(c0 + k, k % NBUF, wave);
-        if (nch >= D) wait_ahead(wave);
-        else wait_vmcnt<0>();
-        wg_barrier();                       // chunk 0 (and the accumulator init above) visible
+            if (k % kProducerWaves == pw && k < nch) issue(k);
+        if (pw == 0) wait_vmcnt<0>();                     // chunk 0 landed
+        wg_barrier();                                     // chunk 0 (and the accumulator init) visible
         for (int it = 0; it < nch; ++it) {
             // slot (it+D)%NBUF held chunk it-1, which the consumers finished before the last barrier
-            if (it + D < nch) {
-                issue(c0 + it + D, (it + D) % NBUF, wave);
-                wait_ahead(wave);           // chunk it+1 has landed
-            } else {
-                wait_vmcnt<0>();
-            }
+            const int ki = it + D, kw = it + 1;
+            if (ki % kProducerWaves == pw && ki < nch) issue(ki);
+            // a wave has at most ONE chunk in flight (D <= 4), plus the index load issued with it (which
+            // hipcc may schedule among the DMAs): vmcnt(0) is exact
+            if (kw % kProducerWaves == pw && kw < nch) wait_vmcnt<0>();   // chunk it+1 landed
             wg_barrier();
         }
+        wait_vmcnt<0>();
     }
 
     // ---- epilogue: the finished tile, whole 16-byte pieces, coalesced ---------------------------
@@ -267,16 +313,10 @@ struct DwArgs {
     int ldx, din4, ldg, dout4, tile, n_chunks, num_rel;
 };
 
-__device__ __forceinline__ int4 row_ids(int4 s, int4 d, int base) {
-    return make_int4(s.x < 0 ? -1 : base + d.x, s.y < 0 ? -1 : base + d.y, s.z < 0 ? -1 : base + d.z,
-                     s.w < 0 ? -1 : base + d.w);
-}
-
 template <int KP, int NP, int NBUF>
 __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     constexpr int MT = KP / 16, NT = NP / 16;
     constexpr int D = NBUF - 1;
-    constexpr int OPS = RowOps<KP>::value + RowOps<NP>::value;
     constexpr int NSL = NT < 4 ? 1 : NT / 4;              // n-slices per consumer wave
     constexpr int RWM = NT < 4 ? 4 / NT : 1;              // consumer waves across m-tiles
     constexpr int MTW = (MT + RWM - 1) / RWM;             // m-tiles per consumer wave
@@ -295,23 +335,6 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     const int i1 = (int)((long)(b + 1) * a.n_chunks / nb);
     const int nch = i1 - i0;
     if (nch <= 0) return;
-
-    auto issue = [&](int i, int buf, int pw) {
-        const int chunk = ldc(a.rel_order, i);
-        const long s4 = ((long)chunk * kChunk + pw * 16) >> 2;
-        const int4 s0 = ldc4(a.slot_src, s4), s1 = ldc4(a.slot_src, s4 + 1), s2 = ldc4(a.slot_src, s4 + 2),
-                   s3 = ldc4(a.slot_src, s4 + 3);
-        const int base = ldc(a.chunk_tile, chunk) * a.tile;
-        const int4 g0 = row_ids(s0, ldc4(a.slot_dstl, s4), base), g1 = row_ids(s1, ldc4(a.slot_dstl, s4 + 1), base),
-                   g2 = row_ids(s2, ldc4(a.slot_dstl, s4 + 2), base), g3 = row_ids(s3, ldc4(a.slot_dstl, s4 + 3), base);
-        issue_rows<KP, kColRead>(a.x, a.ldx, a.din4, s0, s1, s2, s3, ringh + (buf * kChunk + pw * 16) * KP, pw, lane);
-        issue_rows<NP, kColRead>(a.g, a.ldg, a.dout4, g0, g1, g2, g3, ringg + (buf * kChunk + pw * 16) * NP, pw, lane);
-        if (pw == 0) dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
-    };
-    auto wait_ahead = [&](int pw) {
-        if (pw < 1) wait_vmcnt<(D - 1) * (OPS + 1)>();
-        else wait_vmcnt<(D - 1) * OPS>();
-    };
 
     const int cwv = wave - kProducerWaves;
     const int rowl = lane & 15, kq = lane >> 4;
@@ -400,21 +423,39 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
     if (wave < kProducerWaves) {
+        // producers: wave (k % 4) owns chunk k of this workgroup's range (see rgcn_tile_kernel)
+        const int pw = wave;
+        int knext = pw;
+        int idx_h = -1, idx_g = -1;
+        // raw index loads for the wave's next chunk; combined into row ids only at its next turn
+        auto load_idx = [&](int k) {
+            const int kk = k < nch ? k : nch - 1;
+            const int chunk = ldc(a.rel_order, i0 + kk);
+            idx_h = a.slot_src[(size_t)chunk * kChunk + lane];
+            idx_g = a.slot_dstl[(size_t)chunk * kChunk + lane];
+        };
+        load_idx(knext);
+        auto issue = [&](int k) {
+            const int chunk = ldc(a.rel_order, i0 + k), buf = k % NBUF;
+            const int gi = idx_h >= 0 ? ldc(a.chunk_tile, chunk) * a.tile + idx_g : -1;
+            issue_rows<KP, kColRead>(a.x, a.ldx, a.din4, idx_h, ringh + buf * kChunk * KP, lane);
+            issue_rows<NP, kColRead>(a.g, a.ldg, a.dout4, gi, ringg + buf * kChunk * NP, lane);
+            dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
+            knext += kProducerWaves;
+            load_idx(knext);
+        };
 #pragma unroll
         for (int k = 0; k < D; ++k)
-            if (k < nch) issue(i0 + k, k % NBUF, wave);
-        if (nch >= D) wait_ahead(wave);
-        else wait_vmcnt<0>();
+            if (k % kProducerWaves == pw && k < nch) issue(k);
+        if (pw == 0) wait_vmcnt<0>();
         wg_barrier();
         for (int it = 0; it < nch; ++it) {
-            if (it + D < nch) {
-                issue(i0 + it + D, (it + D) % NBUF, wave);
-                wait_ahead(wave);
-            } else {
-                wait_vmcnt<0>();
-            }
+            const int ki = it + D, kw = it + 1;
+            if (ki % kProducerWaves == pw && ki < nch) issue(ki);
+            if (kw % kProducerWaves == pw && kw < nch) wait_vmcnt<0>();
             wg_barrier();
         }
+        wait_vmcnt<0>();
     }
 }
 
@@ -480,7 +521,7 @@ static int check_stride(int ld, int width) {
 template <int KP, int NP>
 static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
     constexpr int NBUF = tile_nbuf<KP>();
-    const size_t lds = sizeof(float) * ((size_t)a.tile * NP + (size_t)NBUF * kChunk * (KP + 2));
+    const size_t lds = sizeof(float) * ((size_t)(a.tile + 1) * NP + (size_t)NBUF * kChunk * (KP + 2));
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
     auto kern = rgcn_tile_kernel<KP, NP, NBUF>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -535,6 +576,8 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.ldo = ldo;
     a.tile = plan->tile;
     a.n_owned = plan->n_owned;
+    const char* dbg = getenv("RGCN_DEBUG_MODE");
+    a.dbg = dbg ? atoi(dbg) : 0;
     return dispatch_tile(padded_width(kin), padded_width(nout), a, plan->n_tiles, (hipStream_t)stream);
 }
 

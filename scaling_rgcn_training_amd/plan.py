@@ -15,7 +15,9 @@ Layout (all int32 / float32, device resident):
   relation-homogeneous (one MFMA B operand) and exactly one LDS-DMA ring slot;
 * the self-loop (PyG ``root``) is relation id ``num_relations`` with one pseudo edge per node;
 * per slot: ``slot_src`` (row to gather, -1 = padding), ``slot_w`` (edge weight
-  ``1 / max(1, c[dst, rel])`` for ``aggr='mean'``, 0 = padding), ``slot_dstl`` (row inside the tile);
+  ``1 / max(1, c[dst, rel])`` for ``aggr='mean'``, 0 = padding), ``slot_dstl`` (row inside the tile,
+  ``tile`` = padding: the kernels keep one dummy accumulator row there); inside a chunk the slots are
+  sorted by ``slot_dstl``, which the forward kernel's run-sum relies on;
   duplicate (src, dst, relation) triples share ONE slot whose weight is the sum of theirs;
 * per chunk: ``chunk_rel``, ``chunk_cnt``, ``chunk_tile``; ``tile_ptr`` gives the tile-major
   chunk ranges (forward / dX kernels) and ``rel_order`` the relation-major order (dW kernel).
@@ -147,7 +149,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     n_slots = n_chunks * CHUNK
     slot_src = torch.full((n_slots,), -1, dtype=torch.int32, device=dev)
     slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
-    slot_dstl = torch.zeros(n_slots, dtype=torch.int32, device=dev)
+    slot_dstl = torch.full((n_slots,), tile, dtype=torch.int32, device=dev)  # padding -> dummy accumulator row
     slot_src[slot] = g_all.to(torch.int32)
     slot_w[slot] = w_all
     slot_dstl[slot] = dstl.to(torch.int32)

@@ -29,7 +29,9 @@ def _check_invariants(plan, n_real_edges):
     assert torch.all((src >= 0) == (col < cnt[:, None]))          # valid slots are a prefix
     assert torch.all(plan.slot_w.view(-1, c)[col >= cnt[:, None]] == 0)
     assert int(cnt.sum()) == n_real_edges + plan.n_owned            # + one root pseudo edge per node
-    assert torch.all(plan.slot_dstl >= 0) and torch.all(plan.slot_dstl < plan.tile)
+    dl = plan.slot_dstl.view(-1, c)
+    assert torch.all(dl[col < cnt[:, None]] < plan.tile) and torch.all(dl[col >= cnt[:, None]] == plan.tile)
+    assert torch.all(dl[:, 1:] >= dl[:, :-1])                      # sorted by destination inside a chunk
     tp = plan.tile_ptr.long()
     assert tp[0] == 0 and tp[-1] == plan.n_chunks and torch.all(tp[1:] > tp[:-1])
     for t in range(plan.n_tiles):                                   # tile-major, rel ascending, root last
