@@ -48,6 +48,17 @@ __device__ __forceinline__ void dma4(const void* gptr, void* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 4, 0, 0);
 }
 
+// Same, through a buffer descriptor: address = rsrc base + voffset (32-bit, per lane); an offset beyond
+// num_records makes the hardware range check feed ZEROS, which is how padding rows and padding columns
+// are produced without a pointer select or 64-bit address arithmetic.
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, float* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    // dword3 0x00020000: raw 32-bit data format (stride 0, offen addressing, range check on num_records)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
 // element `idx` (0..15) of sixteen wave-uniform ints held as 4 x int4 (SGPRs after s_load_dwordx16).
 // A select tree, never an array: runtime-indexed arrays go to scratch.
 __device__ __forceinline__ int pick16(int idx, int4 q0, int4 q1, int4 q2, int4 q3) {

@@ -61,23 +61,40 @@ __global__ void rgcn_pack_kernel(const float* __restrict__ weight, const float* 
 // vector load per chunk, issued right after the previous chunk's DMAs and first used 4 iterations
 // later); a scalar index load issued in the same iteration as its DMAs was a demand miss to HBM
 // per chunk and capped the first version at ~5 us per chunk.
-// W = padded row width (floats).  One global_load_lds_dwordx4 moves 64 lanes x 16 B = RPI rows.
+// W = padded row width (floats).  One LDS-DMA instruction moves 64 lanes x 16 B = RPI rows.
 // idxv: lane l holds the index of chunk row l (< 0 -> the row is zeros).
-template <int W, int MODE>
-__device__ __forceinline__ void issue_rows(const float* __restrict__ base, int ld, int n4, int idxv,
+// BUF = true : the matrix is < 4 GiB and addressed through a buffer descriptor (32-bit offsets, zeros
+//              from the hardware range check) -- ~1/3 of the VALU work per DMA of the pointer form;
+// BUF = false: 64-bit pointers, zeros from a 16-byte zero constant.
+template <int W, int MODE, bool BUF>
+__device__ __forceinline__ void issue_rows(const float* __restrict__ base, unsigned bytes, int ld, int n4, int idxv,
                                            float* slot_base, int lane) {
     constexpr int LPR = W / 4;       // 16-byte lanes per row
     constexpr int RPI = 64 / LPR;    // rows per DMA instruction
     constexpr int NOPS = 64 / RPI;   // DMA instructions per chunk
     const int rsub = lane / LPR;
     const int p = lane % LPR;
+    // all cross-lane index fetches first (one LDS-crossbar round trip for the batch, not one per DMA)
+    int idx[NOPS];
 #pragma unroll
-    for (int i = 0; i < NOPS; ++i) {
-        const int row = i * RPI + rsub;               // row inside the chunk
-        const int idx = __shfl(idxv, row);
-        const int c = p ^ swizzle<MODE, LPR>(row);    // which 16-B column chunk lands at position p
-        const float* gp = (idx >= 0 && c < n4) ? base + (size_t)idx * ld + c * 4 : g_zero16;
-        dma16(gp, slot_base + i * RPI * W);
+    for (int i = 0; i < NOPS; ++i) idx[i] = __shfl(idxv, i * RPI + rsub);
+    if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
+#pragma unroll
+        for (int i = 0; i < NOPS; ++i) {
+            const int row = i * RPI + rsub;               // row inside the chunk
+            const int c = p ^ swizzle<MODE, LPR>(row);    // which 16-B column chunk lands at position p
+            const unsigned off = (idx[i] >= 0 && c < n4) ? (unsigned)idx[i] * (unsigned)(ld * 4) + c * 16 : 0xFFFFFFF0u;
+            dma16_buf(rsrc, off, slot_base + i * RPI * W);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NOPS; ++i) {
+            const int row = i * RPI + rsub;
+            const int c = p ^ swizzle<MODE, LPR>(row);
+            const float* gp = (idx[i] >= 0 && c < n4) ? base + (size_t)idx[i] * ld + c * 4 : g_zero16;
+            dma16(gp, slot_base + i * RPI * W);
+        }
     }
 }
 
@@ -95,11 +112,12 @@ struct TileArgs {
     const float* wp;
     const float* bias;
     float* out;
+    unsigned x_bytes;  // rows * ldx * 4 when that fits 32 bits (buffer-descriptor gathers), else 0
     int ldx, din4, dout, ldo, tile, n_owned;
     int dbg;  // diagnostic ablations (RGCN_DEBUG_MODE env): 1 skip MFMA+accumulate, 2 skip DMA, 4 skip B loads
 };
 
-template <int KP, int NP, int NBUF>
+template <int KP, int NP, int NBUF, bool BUF>
 __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a) {
     constexpr int KT = KP / 16, NT = NP / 16;
     constexpr int D = NBUF - 1;                  // chunks the producers run ahead
@@ -174,41 +192,48 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             const float* wb = wring + buf * kChunk;
             const int* db = dring + buf * kChunk;
             const int nrt = (!active || (a.dbg & 1)) ? 0 : (cnt + 15) >> 4;
-            for (int rt = 0; rt < nrt; ++rt) {
-                const int row = rt * 16 + rowl;
+            // Operands of one 16-row tile.  rows of a chunk are sorted by destination, so equal
+            // destinations are adjacent runs.  d4/w4: rows 4*kq + i (the rows whose MFMA results this lane
+            // holds); dm/dm1: row rowl and its successor; d5: the row after this lane's four.  A run ends at
+            // a change of destination or at the end of the row tile (the next tile is processed after it).
+            struct Ops {
                 f32x4 av[KT];
+                f32x4 w4;
+                i32x4 d4;
+                int dm, dm1, d5;
+            };
+            auto load_ops = [&](Ops& o, int rt) {
+                const int row = rt * 16 + rowl;
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
-                    av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
+                    o.av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
                 }
-                // rows of a chunk are sorted by destination, so equal destinations are adjacent runs.
-                // d4/w4: rows 4*kq + i (the rows whose MFMA results this lane holds); dm/dm1: row rowl
-                // and its successor; d5: the row after this lane's four.  A run ends at a change of
-                // destination or at the end of the row tile (the next tile is processed after this one).
-                const f32x4 w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
-                const i32x4 d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
-                const int dm = db[rt * 16 + rowl];
-                const int dm1 = rowl < 15 ? db[rt * 16 + rowl + 1] : -2;
-                const int d5 = kq < 3 ? db[rt * 16 + 4 * kq + 4] : -2;
-                const bool last_m = dm != dm1;
+                o.w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
+                o.d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
+                o.dm = db[rt * 16 + rowl];
+                o.dm1 = rowl < 15 ? db[rt * 16 + rowl + 1] : -2;
+                o.d5 = kq < 3 ? db[rt * 16 + 4 * kq + 4] : -2;
+            };
+            auto compute = [&](const Ops& o) {
+                const bool last_m = o.dm != o.dm1;
                 // P[m][k] = w_k if row k belongs to the run that ENDS at row m, else 0.  Z = P . Y puts each
                 // run's weighted sum on its last row and zeros elsewhere, so the rows that write below
                 // have pairwise distinct destinations inside this tile.  Y's accumulator registers are
                 // already in B-operand layout for MFMA step i with k = 4*k' + i: no data movement.
                 float pm[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pm[i] = (last_m && d4[i] == dm) ? w4[i] : 0.f;
-                const bool live[4] = {d4[0] != d4[1], d4[1] != d4[2], d4[2] != d4[3], d4[3] != d5};
+                for (int i = 0; i < 4; ++i) pm[i] = (last_m && o.d4[i] == o.dm) ? o.w4[i] : 0.f;
+                const bool live[4] = {o.d4[0] != o.d4[1], o.d4[1] != o.d4[2], o.d4[2] != o.d4[3], o.d4[3] != o.d5};
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < KT; ++j) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], bcur[s][j][0], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], bcur[s][j][1], acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bcur[s][j][2], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bcur[s][j][3], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][0], bcur[s][j][0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][1], bcur[s][j][1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][2], bcur[s][j][2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][3], bcur[s][j][3], acc1, 0, 0, 0);
                     }
                     const f32x4 y = acc0 + acc1;
                     f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
@@ -223,11 +248,22 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                     float old[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        dst[i] = out_lds + (live[i] ? d4[i] : a.tile) * NP + col;
+                        dst[i] = out_lds + (live[i] ? o.d4[i] : a.tile) * NP + col;
                         old[i] = *dst[i];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) *dst[i] = old[i] + z[i];
+                }
+            };
+            // a chunk has at most 4 row tiles: fully unrolled, the NEXT tile's LDS reads are issued before
+            // the current tile's MFMAs so their latency hides under the matrix pipe
+            Ops ops[2];
+            if (nrt > 0) load_ops(ops[0], 0);
+#pragma unroll
+            for (int rt = 0; rt < kChunk / 16; ++rt) {
+                if (rt < nrt) {
+                    if (rt + 1 < nrt) load_ops(ops[(rt + 1) & 1], rt + 1);
+                    compute(ops[rt & 1]);
                 }
             }
             if (swap_b) {
@@ -258,10 +294,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         int idxv = load_idx(knext);
         auto issue = [&](int k) {                         // k == knext
             const int chunk = c0 + k, buf = k % NBUF;
-            if (!(a.dbg & 2))
-                issue_rows<KP, kRowRead>(a.x, a.ldx, a.din4, idxv, ring + buf * kChunk * KP, lane);
-            else
-                issue_rows<KP, kRowRead>(a.x, a.ldx, 0, idxv, ring + buf * kChunk * KP, lane);  // all lanes -> zeros
+            issue_rows<KP, kRowRead, BUF>(a.x, a.x_bytes, a.ldx, (a.dbg & 2) ? 0 : a.din4, idxv,
+                                          ring + buf * kChunk * KP, lane);
             dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
             dma4(a.slot_dstl + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
             knext += kProducerWaves;
@@ -308,12 +342,13 @@ struct DwArgs {
     const int* slot_dstl;
     const float* x;
     const float* g;
+    unsigned x_bytes, g_bytes;
     float* slabs;      // [nblocks + R' + 1][KP*NP]
     float* bias_slabs; // [nblocks][NP]
     int ldx, din4, ldg, dout4, tile, n_chunks, num_rel;
 };
 
-template <int KP, int NP, int NBUF>
+template <int KP, int NP, int NBUF, bool BUF>
 __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     constexpr int MT = KP / 16, NT = NP / 16;
     constexpr int D = NBUF - 1;
@@ -392,28 +427,64 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
             const float* hb = ringh + buf * kChunk * KP;
             const float* gb = ringg + buf * kChunk * NP;
             const float* wb = wring + buf * kChunk;
-            const int nks = (cnt + 3) >> 2;
-            for (int ks = 0; ks < nks; ++ks) {
-                const int row = 4 * ks + kq;   // padding rows were DMA'd as zeros: no masking needed
-                const float wv = wb[row];
-                const int swh = swizzle<kColRead, LPRH>(row), swg = swizzle<kColRead, LPRG>(row);
-                float bv[NSL];
+            // 16 rows (4 MFMA k-steps) per group; operands of the NEXT group are read from LDS before the
+            // current group's MFMAs.  Rows beyond cnt were DMA'd as zeros (w = 0 too): no masking.
+            struct Grp {
+                float av[4][MTW];
+                float gv[4][NSL];
+                float wv[4];
+            };
+            auto load_grp = [&](Grp& o, int grp) {
 #pragma unroll
-                for (int s = 0; s < NSL; ++s) {
-                    const int col = 16 * (ntb + 4 * s) + rowl;
-                    const float gv = gb[row * NP + (((col >> 2) ^ swg) << 2) + (col & 3)];
-                    if (is_root) bsum[s] += gv;
-                    bv[s] = gv * wv;
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 16 * grp + 4 * t + kq;
+                    const int swh = swizzle<kColRead, LPRH>(row), swg = swizzle<kColRead, LPRG>(row);
+                    o.wv[t] = wb[row];
+#pragma unroll
+                    for (int s = 0; s < NSL; ++s) {
+                        const int col = 16 * (ntb + 4 * s) + rowl;
+                        o.gv[t][s] = gb[row * NP + (((col >> 2) ^ swg) << 2) + (col & 3)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) {
+                        const int mt = mtb + RWM * i;
+                        const int col = 16 * (mt < MT ? mt : 0) + rowl;
+                        o.av[t][i] = hb[row * KP + (((col >> 2) ^ swh) << 2) + (col & 3)];
+                    }
                 }
+            };
+            auto compute_grp = [&](const Grp& o) {
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    const int mt = mtb + RWM * i;
-                    if (mt < MT) {
-                        const int col = 16 * mt + rowl;
-                        const float av = hb[row * KP + (((col >> 2) ^ swh) << 2) + (col & 3)];
+                for (int t = 0; t < 4; ++t) {
+                    float bv[NSL];
 #pragma unroll
-                        for (int s = 0; s < NSL; ++s)
-                            acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[s], acc[s][i], 0, 0, 0);
+                    for (int s = 0; s < NSL; ++s) {
+                        if (is_root) bsum[s] += o.gv[t][s];
+                        bv[s] = o.gv[t][s] * o.wv[t];
+                    }
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) {
+                        if (mtb + RWM * i < MT) {
+#pragma unroll
+                            for (int s = 0; s < NSL; ++s)
+                                acc[s][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[t][i], bv[s], acc[s][i], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            const int ngrp = (cnt + 15) >> 4;
+            constexpr bool kPrefetch = MTW * NSL < 16;   // 128x128: the second operand set would spill
+            Grp grp[kPrefetch ? 2 : 1];
+            load_grp(grp[0], 0);
+#pragma unroll
+            for (int gi = 0; gi < kChunk / 16; ++gi) {
+                if (gi < ngrp) {
+                    if (kPrefetch) {
+                        if (gi + 1 < ngrp) load_grp(grp[(gi + 1) & 1], gi + 1);
+                        compute_grp(grp[gi & 1]);
+                    } else {
+                        if (gi > 0) load_grp(grp[0], gi);
+                        compute_grp(grp[0]);
                     }
                 }
             }
@@ -438,8 +509,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         auto issue = [&](int k) {
             const int chunk = ldc(a.rel_order, i0 + k), buf = k % NBUF;
             const int gi = idx_h >= 0 ? ldc(a.chunk_tile, chunk) * a.tile + idx_g : -1;
-            issue_rows<KP, kColRead>(a.x, a.ldx, a.din4, idx_h, ringh + buf * kChunk * KP, lane);
-            issue_rows<NP, kColRead>(a.g, a.ldg, a.dout4, gi, ringg + buf * kChunk * NP, lane);
+            issue_rows<KP, kColRead, BUF>(a.x, a.x_bytes, a.ldx, a.din4, idx_h, ringh + buf * kChunk * KP, lane);
+            issue_rows<NP, kColRead, BUF>(a.g, a.g_bytes, a.ldg, a.dout4, gi, ringg + buf * kChunk * NP, lane);
             dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
             knext += kProducerWaves;
             load_idx(knext);
@@ -512,6 +583,10 @@ static int check_plan(const rgcn_plan_t* p) {
     return RGCN_OK;
 }
 
+// bytes if the matrix can be addressed with 32-bit buffer offsets (the all-ones region is reserved for
+// the out-of-range "zeros" offset), else 0 -> the kernels fall back to 64-bit pointers
+static unsigned fits_u32(size_t bytes) { return bytes < 0xFFFFFF00ull ? (unsigned)bytes : 0u; }
+
 static int check_stride(int ld, int width) {
     if (width < 1 || width > RGCN_MAX_WIDTH) return RGCN_ERR_WIDTH;
     if ((ld % 4) != 0 || ld < ((width + 3) / 4) * 4) return RGCN_ERR_STRIDE;
@@ -523,7 +598,7 @@ static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
     constexpr int NBUF = tile_nbuf<KP>();
     const size_t lds = sizeof(float) * ((size_t)(a.tile + 1) * NP + (size_t)NBUF * kChunk * (KP + 2));
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
-    auto kern = rgcn_tile_kernel<KP, NP, NBUF>;
+    auto kern = a.x_bytes ? rgcn_tile_kernel<KP, NP, NBUF, true> : rgcn_tile_kernel<KP, NP, NBUF, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kThreads), lds, stream, a);
@@ -571,6 +646,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.bias = bias;
     a.out = out;
     a.ldx = ldx;
+    a.x_bytes = fits_u32((size_t)plan->n_nodes * ldx * sizeof(float));
     a.din4 = (kin + 3) / 4;
     a.dout = nout;
     a.ldo = ldo;
@@ -586,7 +662,7 @@ static int launch_dw(const DwArgs& a, int nblocks, hipStream_t stream) {
     constexpr int NBUF = dw_nbuf<KP, NP>();
     const size_t lds = sizeof(float) * ((size_t)NBUF * kChunk * (KP + NP + 1));
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
-    auto kern = rgcn_dw_kernel<KP, NP, NBUF>;
+    auto kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_kernel<KP, NP, NBUF, true> : rgcn_dw_kernel<KP, NP, NBUF, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kThreads), lds, stream, a);
@@ -706,6 +782,8 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.slabs = (float*)workspace;
     a.bias_slabs = a.slabs + dw_slab_floats(plan->num_relations, KP, NP);
     a.ldx = ldx;
+    a.x_bytes = fits_u32((size_t)plan->n_nodes * ldx * sizeof(float));
+    a.g_bytes = fits_u32((size_t)plan->n_owned * ldg * sizeof(float));
     a.din4 = (din + 3) / 4;
     a.ldg = ldg;
     a.dout4 = (dout + 3) / 4;
