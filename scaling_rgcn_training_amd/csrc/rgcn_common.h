@@ -59,6 +59,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
+// 16-byte global load that hipcc can neither sink nor wait for: the consumers prefetch the NEXT chunk's
+// weight fragments with it.  As a plain C++ load the prefetch was sunk below the MFMAs it should overlap
+// (LLVM moves loads towards their first use), which put an L2 round trip in front of every chunk's first
+// MFMA.  Contract (cdna_hip_programming.md 5.7): the outputs are not touched before the caller's own
+// s_waitcnt vmcnt(0); the consumer waves issue no other vector-memory operation in between.
+template <int BYTE_OFFSET>
+__device__ __forceinline__ void prefetch16(f32x4& dst, const f32x4* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(BYTE_OFFSET) : "memory");
+}
+
 // element `idx` (0..15) of sixteen wave-uniform ints held as 4 x int4 (SGPRs after s_load_dwordx16).
 // A select tree, never an array: runtime-indexed arrays go to scratch.
 __device__ __forceinline__ int pick16(int idx, int4 q0, int4 q1, int4 q2, int4 q3) {

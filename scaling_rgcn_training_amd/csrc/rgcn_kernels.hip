@@ -12,10 +12,36 @@
 //                         (relation-major walk; register accumulators; one partial slab per (workgroup, rel))
 //   rgcn_dw_reduce_kernel fixed-order sum of the slabs -> d_weight / d_root / d_bias
 #include <cstdlib>
+#include <type_traits>
 #include "rgcn_common.h"
 #include "../../include/rgcn_mi355x.h"
 
 namespace rgcn {
+
+// Diagnostic build only (-DRGCN_STAMPS, tools/debug/stamps.py): per-segment cycle sums of consumer wave 4
+// and producer wave 0 of every workgroup, written to a buffer no other code reads.  Never in the product .so.
+#ifdef RGCN_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(v) const unsigned long long v = stamp()
+#define STAMP_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define STAMP(v)
+#define STAMP_ADD(acc, a, b)
+#endif
+// compile-time ablations for the diagnostic build: 1 no main MFMA, 2 no run-sum MFMA, 4 no accumulator RMW
+#ifndef RGCN_ABL
+#define RGCN_ABL 0
+#endif
+#ifndef RGCN_SGB
+#define RGCN_SGB 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // weight pack
@@ -98,6 +124,24 @@ __device__ __forceinline__ void issue_rows(const float* __restrict__ base, unsig
     }
 }
 
+// KT x 16 B per lane of one column slice's B fragments (consecutive j are 1 KiB apart)
+template <int KT>
+__device__ __forceinline__ void prefetch_b(f32x4 (&dst)[KT], const f32x4* p) {
+    prefetch16<0>(dst[0], p);
+    if constexpr (KT > 1) prefetch16<1024>(dst[1], p);
+    if constexpr (KT > 2) {
+        prefetch16<2048>(dst[2], p);
+        prefetch16<3072>(dst[3], p);
+    }
+    if constexpr (KT > 4) {
+        const f32x4* q = p + 4 * 64;
+        prefetch16<0>(dst[4], q);
+        prefetch16<1024>(dst[5], q);
+        prefetch16<2048>(dst[6], q);
+        prefetch16<3072>(dst[7], q);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / dX kernel
 // ------------------------------------------------------------------------------------------------
@@ -172,21 +216,40 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                 for (int j = 0; j < KT; ++j)
                     bcur[s][j] = wp4[((size_t)(rel_cur * NT + cw + CW * s) * KT + j) * 64 + lane];
         }
+        // retire these loads in the compiler's scoreboard HERE: otherwise it keeps "maybe pending" waits
+        // in front of the loop's MFMAs, and those s_waitcnt vmcnt(N) would also wait for the asm prefetch
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         wg_barrier();
+#ifdef RGCN_STAMPS
+        unsigned long long st_scal = 0, st_comp = 0, st_bwait = 0, st_bar = 0;
+#endif
         for (int it = 0; it < nch; ++it) {
+            STAMP(t0);
             const int chunk = c0 + it;
             const int buf = it % NBUF;
             const int cnt = ldc(a.chunk_cnt, chunk);
             // prefetch the next chunk's B fragments (L2 resident) under this chunk's MFMAs
             int rel_next = rel_cur;
             if (it + 1 < nch) rel_next = ldc(a.chunk_rel, chunk + 1);
+#ifdef RGCN_STAMPS
+            asm volatile("" ::"s"(cnt), "s"(rel_next));
+#endif
+            STAMP(t1);
             const bool swap_b = active && rel_next != rel_cur && !(a.dbg & 4);
+            // the asm prefetch must never be spilled before its wait (hipcc believes the value is there):
+            // only used where the fragment sets fit the register file comfortably
+            constexpr bool kAsmPrefetch = SL * KT <= 4;
             if (swap_b) {
 #pragma unroll
-                for (int s = 0; s < SL; ++s)
+                for (int s = 0; s < SL; ++s) {
+                    const f32x4* bp = wp4 + ((size_t)(rel_next * NT + cw + CW * s) * KT) * 64 + lane;
+                    if constexpr (kAsmPrefetch) {
+                        prefetch_b<KT>(bnext[s], bp);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < KT; ++j)
-                        bnext[s][j] = wp4[((size_t)(rel_next * NT + cw + CW * s) * KT + j) * 64 + lane];
+                        for (int j = 0; j < KT; ++j) bnext[s][j] = bp[j * 64];
+                    }
+                }
             }
             const float* hb = ring + buf * kChunk * KP;
             const float* wb = wring + buf * kChunk;
@@ -202,6 +265,13 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                 i32x4 d4;
                 int dm, dm1, d5;
             };
+            // per-tile state carried between the pipeline stages below
+            struct Tile {
+                f32x4 y[SL];      // H W_r of the tile (main MFMA result), this wave's column slices
+                f32x4 z[SL][2];   // run sums (two accumulation chains)
+                float* dst[4];    // accumulator rows this lane updates
+                float old[SL][4]; // their previous contents
+            };
             auto load_ops = [&](Ops& o, int rt) {
                 const int row = rt * 16 + rowl;
 #pragma unroll
@@ -215,66 +285,127 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                 o.dm1 = rowl < 15 ? db[rt * 16 + rowl + 1] : -2;
                 o.d5 = kq < 3 ? db[rt * 16 + 4 * kq + 4] : -2;
             };
-            auto compute = [&](const Ops& o) {
-                const bool last_m = o.dm != o.dm1;
-                // P[m][k] = w_k if row k belongs to the run that ENDS at row m, else 0.  Z = P . Y puts each
-                // run's weighted sum on its last row and zeros elsewhere, so the rows that write below
-                // have pairwise distinct destinations inside this tile.  Y's accumulator registers are
-                // already in B-operand layout for MFMA step i with k = 4*k' + i: no data movement.
-                float pm[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pm[i] = (last_m && o.d4[i] == o.dm) ? o.w4[i] : 0.f;
-                const bool live[4] = {o.d4[0] != o.d4[1], o.d4[1] != o.d4[2], o.d4[2] != o.d4[3], o.d4[3] != o.d5};
+            // stage A: y = H_tile . W_r (16 MFMAs per column slice, two independent chains)
+            auto stage_a = [&](const Ops& o, Tile& t) {
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < KT; ++j) {
+                        if (RGCN_ABL & 1) {
+                            acc0 += o.av[j];
+                            continue;
+                        }
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][0], bcur[s][j][0], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][1], bcur[s][j][1], acc1, 0, 0, 0);
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][2], bcur[s][j][2], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][3], bcur[s][j][3], acc1, 0, 0, 0);
                     }
-                    const f32x4 y = acc0 + acc1;
-                    f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], y[0], z0, 0, 0, 0);
-                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], y[1], z1, 0, 0, 0);
-                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], y[2], z0, 0, 0, 0);
-                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], y[3], z1, 0, 0, 0);
-                    const f32x4 z = z0 + z1;
-                    const int col = 16 * (cw + CW * s) + rowl;
-                    // rows that do not end a run (and padding, destination == tile) go to the dummy row
-                    float* dst[4];
-                    float old[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        dst[i] = out_lds + (live[i] ? o.d4[i] : a.tile) * NP + col;
-                        old[i] = *dst[i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) *dst[i] = old[i] + z[i];
+                    t.y[s] = acc0 + acc1;
                 }
             };
-            // a chunk has at most 4 row tiles: fully unrolled, the NEXT tile's LDS reads are issued before
-            // the current tile's MFMAs so their latency hides under the matrix pipe
-            Ops ops[2];
-            if (nrt > 0) load_ops(ops[0], 0);
+            // stage B: Z = P . Y.  P[m][k] = w_k if row k belongs to the run that ENDS at row m, else 0, so
+            // each run's weighted sum lands on its last row and the rows that write in stage C have
+            // pairwise distinct destinations inside the tile.  Y's accumulator registers are already in
+            // B-operand layout for MFMA step i with k = 4*k' + i: no data movement.  The accumulator reads
+            // of stage C are issued here (after the previous tile's stage-C writes in program order).
+            auto stage_b = [&](const Ops& o, Tile& t) {
+                const bool last_m = o.dm != o.dm1;
+                float pm[4];
 #pragma unroll
-            for (int rt = 0; rt < kChunk / 16; ++rt) {
-                if (rt < nrt) {
-                    if (rt + 1 < nrt) load_ops(ops[(rt + 1) & 1], rt + 1);
-                    compute(ops[rt & 1]);
+                for (int i = 0; i < 4; ++i) pm[i] = (last_m && o.d4[i] == o.dm) ? o.w4[i] : 0.f;
+                const bool live[4] = {o.d4[0] != o.d4[1], o.d4[1] != o.d4[2], o.d4[2] != o.d4[3], o.d4[3] != o.d5};
+                // rows that do not end a run (and padding, destination == tile) go to the dummy row
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t.dst[i] = out_lds + (live[i] ? o.d4[i] : a.tile) * NP + 16 * cw + rowl;
+#pragma unroll
+                for (int s = 0; s < SL; ++s) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t.old[s][i] = (RGCN_ABL & 4) ? 0.f : t.dst[i][16 * CW * s];
+                    f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+                    if (RGCN_ABL & 2) {
+                        t.z[s][0] = t.y[s] * pm[0];
+                        t.z[s][1] = t.y[s] * pm[1] + pm[2] + pm[3];
+                        continue;
+                    }
+                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], t.y[s][0], z0, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], t.y[s][1], z1, 0, 0, 0);
+                    t.z[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], t.y[s][2], z0, 0, 0, 0);
+                    t.z[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], t.y[s][3], z1, 0, 0, 0);
                 }
+            };
+            // stage C: plain read-modify-write of the tile accumulator (this wave owns these columns)
+            auto stage_c = [&](Tile& t) {
+#pragma unroll
+                for (int s = 0; s < SL; ++s) {
+                    const f32x4 z = t.z[s][0] + t.z[s][1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (RGCN_ABL & 4) asm volatile("" ::"v"(t.old[s][i] + z[i]), "v"(t.dst[i]));
+                        else t.dst[i][16 * CW * s] = t.old[s][i] + z[i];
+                    }
+                }
+            };
+            // One straight-line block per tile count (1..4) so hipcc can interleave freely.  Software
+            // pipeline: A(t+1) is issued before the tail of tile t, and stage C runs a further step behind,
+            // so the VALU / LDS work of one tile sits in the shadow of the next tiles' MFMAs instead of
+            // idling the matrix pipe (one MFMA-issuing wave per SIMD: nothing else would fill it).
+            auto consume = [&](auto nrt_c) {
+                constexpr int NRT = decltype(nrt_c)::value;
+                Ops ops[NRT];
+                Tile tl[NRT];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) load_ops(ops[t], t);
+#pragma unroll
+                for (int step = 0; step < NRT + 2; ++step) {
+                    if (step < NRT) stage_a(ops[step], tl[step]);
+                    if (step >= 2) stage_c(tl[step - 2]);
+                    if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1]);
+                }
+                // ask the scheduler for MFMA / VALU / LDS interleaving: an MFMA holds the issue port for 8
+                // of its 32 cycles, the other 24 take ~5 single-issue instructions of the same wave
+#if RGCN_SGB
+#pragma unroll
+                for (int i = 0; i < NRT * SL * (4 * KT + 4); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, RGCN_SGB, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);   // 1 DS
+                }
+#endif
+            };
+            switch (nrt) {
+                case 1: consume(std::integral_constant<int, 1>{}); break;
+                case 2: consume(std::integral_constant<int, 2>{}); break;
+                case 3: consume(std::integral_constant<int, 3>{}); break;
+                case 4: consume(std::integral_constant<int, 4>{}); break;
+                default: break;
             }
+            STAMP(t2);
             if (swap_b) {
+                if constexpr (kAsmPrefetch) wait_vmcnt<0>();   // the asm prefetch (this wave's only vector-memory traffic)
 #pragma unroll
                 for (int s = 0; s < SL; ++s)
 #pragma unroll
                     for (int j = 0; j < KT; ++j) bcur[s][j] = bnext[s][j];
+#ifdef RGCN_STAMPS
+                asm volatile("" ::"v"(bcur[0][0][0]), "v"(bcur[SL - 1][KT - 1][3]));
+#endif
             }
             rel_cur = rel_next;
+            STAMP(t3);
             wg_barrier();
+            STAMP(t4);
+            STAMP_ADD(st_scal, t0, t1);
+            STAMP_ADD(st_comp, t1, t2);
+            STAMP_ADD(st_bwait, t2, t3);
+            STAMP_ADD(st_bar, t3, t4);
         }
+#ifdef RGCN_STAMPS
+        if (g_stamps && cwv == 0 && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            o[0] = st_scal; o[1] = st_comp; o[2] = st_bwait; o[3] = st_bar;
+        }
+#endif
         // tell the waitcnt pass that no consumer load is pending when the producer code (next in program
         // order) reuses these registers; otherwise it waits vmcnt(0) between the prologue DMAs
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -306,16 +437,33 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             if (k % kProducerWaves == pw && k < nch) issue(k);
         if (pw == 0) wait_vmcnt<0>();                     // chunk 0 landed
         wg_barrier();                                     // chunk 0 (and the accumulator init) visible
+#ifdef RGCN_STAMPS
+        unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
+#endif
         for (int it = 0; it < nch; ++it) {
             // slot (it+D)%NBUF held chunk it-1, which the consumers finished before the last barrier
             const int ki = it + D, kw = it + 1;
+            STAMP(p0);
             if (ki % kProducerWaves == pw && ki < nch) issue(ki);
+            STAMP(p1);
             // a wave has at most ONE chunk in flight (D <= 4), plus the index load issued with it (which
             // hipcc may schedule among the DMAs): vmcnt(0) is exact
             if (kw % kProducerWaves == pw && kw < nch) wait_vmcnt<0>();   // chunk it+1 landed
+            STAMP(p2);
             wg_barrier();
+            STAMP(p3);
+            STAMP_ADD(sp_issue, p0, p1);
+            STAMP_ADD(sp_wait, p1, p2);
+            STAMP_ADD(sp_bar, p2, p3);
         }
         wait_vmcnt<0>();
+#ifdef RGCN_STAMPS
+        if (g_stamps && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
+            if (pw == 1) o[7] = nch;
+        }
+#endif
     }
 
     // ---- epilogue: the finished tile, whole 16-byte pieces, coalesced ---------------------------
@@ -700,6 +848,12 @@ static size_t dw_slab_floats(int num_rel, int KP, int NP) { return (size_t)(kDwB
 using namespace rgcn;
 
 extern "C" int rgcn_abi_version(void) { return RGCN_ABI_VERSION; }
+
+#ifdef RGCN_STAMPS
+extern "C" int rgcn_debug_set_stamps(unsigned long long* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(rgcn::g_stamps), &p, sizeof(p));
+}
+#endif
 
 extern "C" const char* rgcn_status_string(int status) {
     switch (status) {

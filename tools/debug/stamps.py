@@ -1,0 +1,37 @@
+"""Diagnostic: per-segment cycle shares of the tile kernel's consumer / producer loops (stamp build).
+Builds librgcn_stamps.so with -DRGCN_STAMPS and runs one forward launch at the given size."""
+import ctypes, os, subprocess, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "gpurun_out", "librgcn_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+abl = os.environ.get("RGCN_ABL", "0")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRGCN_STAMPS", "-DRGCN_ABL=" + abl, "-DRGCN_SGB=" + os.environ.get("RGCN_SGB", "0"),
+                os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_kernels.hip"), "-o", so], check=True)
+from scaling_rgcn_training_amd import _lib
+_lib.LIB_PATH = so
+lib = _lib.load()
+from scaling_rgcn_training_amd import plan as P
+import bench
+n, e = int(sys.argv[1]), int(sys.argv[2])
+dev = torch.device("cuda:0")
+ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, 32, 64, 64, dev)
+plans = P.build_graph_plans(ei, et, n, 32, 256)
+fp = plans.fwd
+stamps = torch.zeros(fp.n_tiles * 8, dtype=torch.int64, device=dev)
+lib.rgcn_debug_set_stamps.argtypes = [ctypes.c_void_p]
+assert lib.rgcn_debug_set_stamps(stamps.data_ptr()) == 0
+out = torch.empty(n, 64, device=dev)
+pk = _lib.pack_weights(w, root, False)
+for _ in range(2):
+    _lib.fwd(_lib.plan_struct(fp), x, 64, pk, None, out, 64)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().reshape(-1, 8).astype(np.float64)
+nch = s[:, 7]
+tot_c = s[:, 0:4].sum(1); tot_p = s[:, 4:7].sum(1)
+print("SGB", os.environ.get("RGCN_SGB", "0"), "ABL", abl, "tiles", len(s), "chunks/tile mean", nch.mean())
+names = ["cons scalar-loads", "cons compute", "cons B-wait", "cons barrier", "prod issue", "prod dma-wait", "prod barrier"]
+for i, nm in enumerate(names):
+    print(f"{nm:20s} {s[:, i].sum() / nch.sum():9.1f} cycles/chunk")
+print(f"consumer loop total {tot_c.sum() / nch.sum():9.1f} cycles/chunk; producer wave0 loop total {tot_p.sum() / nch.sum():9.1f}")
