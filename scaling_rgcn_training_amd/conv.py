@@ -39,10 +39,10 @@ def tile_for(in_channels: int, out_channels: int) -> int:
     """Output nodes per tile: the tile accumulator [tile, pad(width)] fp32 shares the 160 KiB LDS with
     the DMA ring; both directions (forward: width = out, dX: width = in) use the same tile so one
     pair of plans serves a layer."""
-    widest = max(_lib.padded_width(in_channels), _lib.padded_width(out_channels))
-    if widest == 0:
+    if not (1 <= in_channels <= 128 and 1 <= out_channels <= 128):
         raise ValueError(f"RGCNConv widths must be in 1..128, got {in_channels}->{out_channels}")
-    return 128 if widest == 128 else 256
+    widest = max(in_channels, out_channels)
+    return 128 if widest > 64 else 256
 
 
 class DistContext:

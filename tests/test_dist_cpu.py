@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the edge partition, the per-layer all-gather and
+the weight-gradient all-reduce around the numpy plan walk (tests/plan_emulator.py stands in for the
+HIP kernels, which need a GPU), and must reproduce the single-rank result.  CPU only."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import rgcn_oracle as O
+    from scaling_rgcn_training_amd import dist as rdist, plan as P
+    from tests.plan_emulator import emulate_dw, emulate_spmm
+    n, e, r, din, dout, tile = 1000, 9000, 5, 8, 6, 64
+    ei, et = O.synthetic_graph(n, e, r, seed=4)
+    w, root, bias = O.synthetic_params(r, din, dout, seed=4)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, din, generator=g).double()
+    dg = torch.randn(n, dout, generator=g).double()
+    w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0).astype(np.float64)
+    ctx = rdist.make_context(n, tile)
+    assert ctx is not None and ctx.world == world and ctx.rank == rank
+    plans = rdist.rank_plans(ei, et, n, r, tile, "mean", rank, world)
+    rows = ctx.rows_per_rank
+    # forward: own rows into the own slice of the gathered buffer, then ONE all-gather (conv.py forward)
+    full = torch.zeros(world * rows, dout, dtype=torch.float64)
+    mine = full[rank * rows:(rank + 1) * rows]
+    if plans.fwd.n_owned:
+        mine[:plans.fwd.n_owned] = torch.from_numpy(emulate_spmm(plans.fwd, x.numpy(), w_all, bias.numpy()))
+    dist.all_gather_into_tensor(full, mine.clone())
+    out = full[:n]
+    # backward dX on the transposed plan, same gather
+    fullx = torch.zeros(world * rows, din, dtype=torch.float64)
+    minex = fullx[rank * rows:(rank + 1) * rows]
+    if plans.bwd.n_owned:
+        minex[:plans.bwd.n_owned] = torch.from_numpy(
+            emulate_spmm(plans.bwd, dg.numpy(), np.transpose(w_all, (0, 2, 1))))
+    dist.all_gather_into_tensor(fullx, minex.clone())
+    dx = fullx[:n]
+    # weight gradients: partial over the own rows, all-reduced
+    dw = torch.zeros(r + 1, din, dout, dtype=torch.float64)
+    if plans.fwd.n_owned:
+        b, e_ = plans.fwd.node_begin, plans.fwd.node_end
+        dw = torch.from_numpy(emulate_dw(plans.fwd, x.numpy(), dg.numpy()[b:e_], r + 1, din, dout))
+    dist.all_reduce(dw)
+    if rank == 0:
+        ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(),
+                                       dg.numpy())
+        np.testing.assert_allclose(out.numpy(), ref, rtol=1e-6, atol=1e-6)   # w is fp32 1/c: 6e-8 relative
+        np.testing.assert_allclose(dx.numpy(), gr["x"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(dw[:-1].numpy(), gr["weight"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(dw[-1].numpy(), gr["root"], rtol=1e-6, atol=1e-6)
+        # a rank's slots are exactly the single-rank slots of its tiles (bit-identical per-row results)
+        single = P.build_graph_plans(ei, et, n, r, tile)
+        one = emulate_spmm(single.fwd, x.numpy(), w_all, bias.numpy())
+        assert np.array_equal(one, out.numpy())
+        ret.put("ok")
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_partition_matches_single_rank():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert ret.get(timeout=5) == "ok"
