@@ -60,8 +60,16 @@ def _worker(rank, world, port, ret):
     if rank == 0:
         assert np.array_equal(single[0], part[0]), "partitioned forward must be bit-identical (tile-aligned ranges)"
         assert np.array_equal(single[1], part[1]), "partitioned dX must be bit-identical"
-        for a, b in zip(single[2:], part[2:]):   # weight grads: partial sums all-reduced, order differs
-            np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-5)
+        # weight grads: per-rank partial sums all-reduced -> summation order differs; both must meet the
+        # parity criterion against the float64 oracle
+        from oracle.tolerance import abs_condition, assert_close
+        _, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(),
+                                     (bias + 0.25).numpy(), dg.numpy())
+        _, c = abs_condition(x, ei, et, w, root, bias + 0.25, dg)
+        for res in (single, part):
+            assert_close(res[2], gr["weight"], c["weight"], "d_weight")
+            assert_close(res[3], gr["root"], c["root"], "d_root")
+            assert_close(res[4], gr["bias"], c["bias"], "d_bias")
         ret.put("ok")
     dist.destroy_process_group()
 
