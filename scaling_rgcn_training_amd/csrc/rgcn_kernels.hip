@@ -151,7 +151,7 @@ struct TileArgs {
     const int* chunk_cnt;
     const int* slot_src;
     const float* slot_w;
-    const int* slot_dstl;
+    const int* slot_acc;
     const float* x;
     const float* wp;
     const float* bias;
@@ -219,6 +219,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         // retire these loads in the compiler's scoreboard HERE: otherwise it keeps "maybe pending" waits
         // in front of the loop's MFMAs, and those s_waitcnt vmcnt(N) would also wait for the asm prefetch
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        int cnt_pre = ldc(a.chunk_cnt, c0);
+        int rel_pre = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bwait = 0, st_bar = 0;
@@ -227,10 +229,11 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             STAMP(t0);
             const int chunk = c0 + it;
             const int buf = it % NBUF;
-            const int cnt = ldc(a.chunk_cnt, chunk);
-            // prefetch the next chunk's B fragments (L2 resident) under this chunk's MFMAs
-            int rel_next = rel_cur;
-            if (it + 1 < nch) rel_next = ldc(a.chunk_rel, chunk + 1);
+            // chunk metadata arrives one iteration ahead (scalar loads issued a whole chunk earlier)
+            const int cnt = cnt_pre;
+            const int rel_next = rel_pre;
+            if (it + 1 < nch) cnt_pre = ldc(a.chunk_cnt, chunk + 1);
+            if (it + 2 < nch) rel_pre = ldc(a.chunk_rel, chunk + 2);
 #ifdef RGCN_STAMPS
             asm volatile("" ::"s"(cnt), "s"(rel_next));
 #endif
@@ -255,15 +258,15 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             const float* wb = wring + buf * kChunk;
             const int* db = dring + buf * kChunk;
             const int nrt = (!active || (a.dbg & 1)) ? 0 : (cnt + 15) >> 4;
-            // Operands of one 16-row tile.  rows of a chunk are sorted by destination, so equal
-            // destinations are adjacent runs.  d4/w4: rows 4*kq + i (the rows whose MFMA results this lane
-            // holds); dm/dm1: row rowl and its successor; d5: the row after this lane's four.  A run ends at
-            // a change of destination or at the end of the row tile (the next tile is processed after it).
+            // Operands of one 16-row tile.  Rows of a chunk are sorted by destination, so equal
+            // destinations are adjacent runs; a run ends at a change of destination or at the end of the row
+            // tile (the next tile is processed after it).  Which slot ends each run, and which accumulator
+            // row each slot writes, comes precomputed with the plan (slot_acc): the consumers' vector
+            // instructions compete with the fp32 MFMAs for the same SIMD pipe, so none are spent on it here.
             struct Ops {
                 f32x4 av[KT];
-                f32x4 w4;
-                i32x4 d4;
-                int dm, dm1, d5;
+                f32x4 w4;   // weights of rows 4*kq + i (the rows whose MFMA results this lane holds)
+                i32x4 d4;   // their run metadata from the plan: accumulator row | run-end position << 16
             };
             // per-tile state carried between the pipeline stages below
             struct Tile {
@@ -281,9 +284,6 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                 }
                 o.w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
                 o.d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
-                o.dm = db[rt * 16 + rowl];
-                o.dm1 = rowl < 15 ? db[rt * 16 + rowl + 1] : -2;
-                o.d5 = kq < 3 ? db[rt * 16 + 4 * kq + 4] : -2;
             };
             // stage A: y = H_tile . W_r (16 MFMAs per column slice, two independent chains)
             auto stage_a = [&](const Ops& o, Tile& t) {
@@ -310,14 +310,15 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             // B-operand layout for MFMA step i with k = 4*k' + i: no data movement.  The accumulator reads
             // of stage C are issued here (after the previous tile's stage-C writes in program order).
             auto stage_b = [&](const Ops& o, Tile& t) {
-                const bool last_m = o.dm != o.dm1;
                 float pm[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pm[i] = (last_m && o.d4[i] == o.dm) ? o.w4[i] : 0.f;
-                const bool live[4] = {o.d4[0] != o.d4[1], o.d4[1] != o.d4[2], o.d4[2] != o.d4[3], o.d4[3] != o.d5};
-                // rows that do not end a run (and padding, destination == tile) go to the dummy row
-#pragma unroll
-                for (int i = 0; i < 4; ++i) t.dst[i] = out_lds + (live[i] ? o.d4[i] : a.tile) * NP + 16 * cw + rowl;
+                for (int i = 0; i < 4; ++i) {
+                    // row 4*kq + i belongs to the run that ends at tile row (d >> 16); this lane supplies
+                    // P[m = rowl][k = 4*kq + i]
+                    pm[i] = ((unsigned)o.d4[i] >> 16) == (unsigned)rowl ? o.w4[i] : 0.f;
+                    // run ends write their destination row, everything else the dummy row (already encoded)
+                    t.dst[i] = out_lds + (o.d4[i] & 0xFFFF) * NP + 16 * cw + rowl;
+                }
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
 #pragma unroll
@@ -354,10 +355,17 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                 constexpr int NRT = decltype(nrt_c)::value;
                 Ops ops[NRT];
                 Tile tl[NRT];
-#pragma unroll
-                for (int t = 0; t < NRT; ++t) load_ops(ops[t], t);
+                // LDS reads of tile t+1 are issued BEFORE the MFMAs of tile t and pinned there with
+                // sched_barrier: left alone, hipcc sinks every ds_read_b128 to just in front of the four
+                // MFMAs that use it and waits lgkmcnt(0) -- 16 exposed LDS round trips per chunk.
+                load_ops(ops[0], 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int step = 0; step < NRT + 2; ++step) {
+                    if (step + 1 < NRT) {
+                        load_ops(ops[step + 1], step + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (step < NRT) stage_a(ops[step], tl[step]);
                     if (step >= 2) stage_c(tl[step - 2]);
                     if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1]);
@@ -428,7 +436,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             issue_rows<KP, kRowRead, BUF>(a.x, a.x_bytes, a.ldx, (a.dbg & 2) ? 0 : a.din4, idxv,
                                           ring + buf * kChunk * KP, lane);
             dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
-            dma4(a.slot_dstl + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
+            dma4(a.slot_acc + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
             knext += kProducerWaves;
             idxv = load_idx(knext);                       // youngest op of this wave from here on
         };
@@ -678,7 +686,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     }
 }
 
-// slabs -> gradients, fixed summation order (block index ascending) => bitwise reproducible
+// slabs -> gradients, fixed summation order (block index ascending) => bitwise reproducible.
+// grid = (R' + 2, parts): blockIdx.x = relation (R' = root, R'+1 = bias), blockIdx.y = slice of the elements.
+// The workgroups whose chunk range touches relation r are a contiguous run [b_lo, b_hi].
 __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
                                       const int* __restrict__ rel_order, const int* __restrict__ chunk_rel,
                                       int n_chunks, int nblocks, int num_rel, int KP, int NP, int din, int dout,
@@ -686,7 +696,7 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
                                       float* __restrict__ d_bias) {
     const int r = blockIdx.x;
     if (r == num_rel + 1) {
-        if (d_bias == nullptr) return;
+        if (d_bias == nullptr || blockIdx.y != 0) return;
         for (int n = threadIdx.x; n < dout; n += blockDim.x) {
             float s = 0.f;
             for (int b = 0; b < nblocks; ++b) s += bias_slabs[(size_t)b * NP + n];
@@ -696,16 +706,28 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
     }
     float* dst = r < num_rel ? (d_weight ? d_weight + (size_t)r * din * dout : nullptr) : d_root;
     if (dst == nullptr) return;
-    for (int e = threadIdx.x; e < din * dout; e += blockDim.x) {
-        const int k = e / dout, n = e - k * dout;
-        float s = 0.f;
+    __shared__ int s_lo, s_hi;
+    if (threadIdx.x == 0) {
+        int lo = nblocks, hi = -1;
         for (int b = 0; b < nblocks; ++b) {
             const int i0 = (int)((long)b * n_chunks / nblocks);
             const int i1 = (int)((long)(b + 1) * n_chunks / nblocks);
             if (i1 <= i0) continue;
             const int first = chunk_rel[rel_order[i0]], last = chunk_rel[rel_order[i1 - 1]];
-            if (r >= first && r <= last) s += slabs[(size_t)(b + r) * KP * NP + (size_t)k * NP + n];
+            if (r >= first && r <= last) {
+                lo = b < lo ? b : lo;
+                hi = b;
+            }
         }
+        s_lo = lo;
+        s_hi = hi;
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < din * dout; e += gridDim.y * blockDim.x) {
+        const int k = e / dout, n = e - k * dout;
+        float s = 0.f;
+        for (int b = lo; b <= hi; ++b) s += slabs[(size_t)(b + r) * KP * NP + (size_t)k * NP + n];
         dst[e] = s;
     }
 }
@@ -723,9 +745,9 @@ constexpr int dw_nbuf() { return (KP == 128 || NP == 128) ? 2 : 4; }
 static int check_plan(const rgcn_plan_t* p) {
     if (p == nullptr) return RGCN_ERR_NULL;
     if (!p->tile_ptr || !p->chunk_rel || !p->chunk_cnt || !p->chunk_tile || !p->rel_order || !p->slot_src ||
-        !p->slot_w || !p->slot_dstl)
+        !p->slot_w || !p->slot_dstl || !p->slot_acc)
         return RGCN_ERR_NULL;
-    if (p->n_nodes <= 0 || p->n_owned <= 0 || p->num_relations <= 0 || p->tile <= 0 || (p->tile % 16) != 0 ||
+    if (p->n_nodes <= 0 || p->n_owned <= 0 || p->num_relations <= 0 || p->tile <= 0 || (p->tile % 16) != 0 || p->tile > 32768 ||
         p->n_tiles <= 0 || p->n_chunks < p->n_tiles || (long)p->n_tiles * p->tile < p->n_owned)
         return RGCN_ERR_PLAN;
     return RGCN_OK;
@@ -788,7 +810,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.chunk_cnt = plan->chunk_cnt;
     a.slot_src = plan->slot_src;
     a.slot_w = plan->slot_w;
-    a.slot_dstl = plan->slot_dstl;
+    a.slot_acc = plan->slot_acc;
     a.x = x;
     a.wp = packed;
     a.bias = bias;
@@ -946,7 +968,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.num_rel = plan->num_relations;
     st = dispatch_dw(KP, NP, a, kDwBlocks, s);
     if (st != RGCN_OK) return st;
-    hipLaunchKernelGGL(rgcn_dw_reduce_kernel, dim3(plan->num_relations + 2), dim3(256), 0, s, a.slabs, a.bias_slabs,
+    hipLaunchKernelGGL(rgcn_dw_reduce_kernel, dim3(plan->num_relations + 2, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs, a.bias_slabs,
                        plan->rel_order, plan->chunk_rel, plan->n_chunks, kDwBlocks, plan->num_relations, KP, NP, din,
                        dout, d_weight, d_root, d_bias);
     return (int)hipGetLastError();

@@ -17,7 +17,8 @@ Layout (all int32 / float32, device resident):
 * per slot: ``slot_src`` (row to gather, -1 = padding), ``slot_w`` (edge weight
   ``1 / max(1, c[dst, rel])`` for ``aggr='mean'``, 0 = padding), ``slot_dstl`` (row inside the tile,
   ``tile`` = padding: the kernels keep one dummy accumulator row there); inside a chunk the slots are
-  sorted by ``slot_dstl``, which the forward kernel's run-sum relies on;
+  sorted by ``slot_dstl``, which the forward kernel's run-sum relies on; ``slot_acc`` packs what that
+  run-sum needs per slot (accumulator row | run-end position << 16, see ``run_metadata``);
   duplicate (src, dst, relation) triples share ONE slot whose weight is the sum of theirs;
 * per chunk: ``chunk_rel``, ``chunk_cnt``, ``chunk_tile``; ``tile_ptr`` gives the tile-major
   chunk ranges (forward / dX kernels) and ``rel_order`` the relation-major order (dW kernel).
@@ -55,6 +56,7 @@ class TilePlan:
     slot_src: Tensor      # int32 [n_chunks * CHUNK]
     slot_w: Tensor        # float32 [n_chunks * CHUNK]
     slot_dstl: Tensor     # int32 [n_chunks * CHUNK]
+    slot_acc: Tensor      # int32 [n_chunks * CHUNK]  accumulator row | run-end position << 16
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -68,7 +70,7 @@ class TilePlan:
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (
             self.tile_ptr, self.chunk_rel, self.chunk_cnt, self.chunk_tile, self.rel_order,
-            self.slot_src, self.slot_w, self.slot_dstl))
+            self.slot_src, self.slot_w, self.slot_dstl, self.slot_acc))
 
 
 def edge_weights(src: Tensor, dst: Tensor, rel: Tensor, num_relations: int, aggr: str = "mean") -> Tensor:
@@ -153,6 +155,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     slot_src[slot] = g_all.to(torch.int32)
     slot_w[slot] = w_all
     slot_dstl[slot] = dstl.to(torch.int32)
+    slot_acc = run_metadata(slot_dstl, tile)
     grp_of_chunk = torch.repeat_interleave(torch.arange(n_groups, device=dev), gch)
     idx_in_grp = torch.arange(n_chunks, device=dev) - chunk_base[grp_of_chunk]
     chunk_cnt = torch.clamp(gcnt[grp_of_chunk] - idx_in_grp * CHUNK, max=CHUNK).to(torch.int32)
@@ -168,7 +171,28 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     num_relations=num_relations, tile=tile, n_tiles=n_tiles, n_chunks=n_chunks,
                     n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
-                    slot_dstl=slot_dstl)
+                    slot_dstl=slot_dstl, slot_acc=slot_acc)
+
+
+ROWS_PER_MFMA_TILE = 16
+
+
+def run_metadata(slot_dstl: Tensor, tile: int) -> Tensor:
+    """Per slot, for the forward kernel's run-sum (csrc/rgcn_kernels.hip stage B/C), precomputed here so
+    the kernel spends no vector instructions on it: inside every 16-slot MFMA row tile, slots with equal
+    destination are adjacent (chunks are sorted by destination) and form a RUN; the run's sum is written by
+    its LAST slot only.  low 16 bits: accumulator row the slot writes (its destination if it ends a run,
+    else the dummy row ``tile``; padding slots carry destination ``tile`` already); high 16 bits: position
+    (0..15) inside the row tile of the slot that ends this slot's run."""
+    g = ROWS_PER_MFMA_TILE
+    d = slot_dstl.view(-1, g).to(torch.int64)
+    nxt = torch.cat([d[:, 1:], torch.full_like(d[:, :1], -1)], dim=1)
+    is_end = d != nxt                                    # last column always ends (next = -1)
+    pos = torch.arange(g, device=d.device).expand_as(d)
+    endpos = torch.where(is_end, pos, torch.full_like(pos, g))
+    runend = torch.flip(torch.cummin(torch.flip(endpos, [1]), dim=1).values, [1])
+    acc = torch.where(is_end, d, torch.full_like(d, tile))
+    return (acc | (runend << 16)).to(torch.int32).reshape(-1)
 
 
 @dataclass

@@ -32,6 +32,16 @@ def _check_invariants(plan, n_real_edges):
     dl = plan.slot_dstl.view(-1, c)
     assert torch.all(dl[col < cnt[:, None]] < plan.tile) and torch.all(dl[col >= cnt[:, None]] == plan.tile)
     assert torch.all(dl[:, 1:] >= dl[:, :-1])                      # sorted by destination inside a chunk
+    # run metadata: inside each 16-slot row tile, exactly the LAST slot of a run of equal destinations
+    # carries that destination, all others the dummy row; every slot points at its run's last slot
+    acc = (plan.slot_acc & 0xFFFF).view(-1, 16).long()
+    rend = (plan.slot_acc >> 16).view(-1, 16).long()
+    d16 = plan.slot_dstl.view(-1, 16).long()
+    for t in range(min(acc.shape[0], 400)):
+        for i in range(16):
+            j = int(rend[t, i])
+            assert i <= j < 16 and torch.all(d16[t, i:j + 1] == d16[t, i]) and (j == 15 or d16[t, j + 1] != d16[t, i])
+            assert acc[t, i] == (d16[t, i] if i == j else plan.tile)
     tp = plan.tile_ptr.long()
     assert tp[0] == 0 and tp[-1] == plan.n_chunks and torch.all(tp[1:] > tp[:-1])
     for t in range(plan.n_tiles):                                   # tile-major, rel ascending, root last
