@@ -64,7 +64,7 @@ typedef struct rgcn_plan {
     const int32_t* chunk_cnt;  /* [n_chunks] valid slots (1..64), a prefix of the chunk */
     const int32_t* chunk_tile; /* [n_chunks] */
     const int32_t* rel_order;  /* [n_chunks] chunk ids sorted by (relation, tile) */
-    const int32_t* slot_src;   /* [n_chunks * 64] row to gather, -1 = padding */
+    const int32_t* slot_src;   /* [n_chunks * 64] row to gather; padding = n_nodes (one past the last row) */
     const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */
     const int32_t* slot_dstl;  /* [n_chunks * 64] row inside the tile, ascending inside a chunk; padding = tile */
     const int32_t* slot_acc;   /* [n_chunks * 64] forward run-sum metadata per slot: low 16 bits = accumulator row

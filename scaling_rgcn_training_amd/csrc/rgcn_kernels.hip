@@ -88,41 +88,58 @@ __global__ void rgcn_pack_kernel(const float* __restrict__ weight, const float* 
 // later); a scalar index load issued in the same iteration as its DMAs was a demand miss to HBM
 // per chunk and capped the first version at ~5 us per chunk.
 // W = padded row width (floats).  One LDS-DMA instruction moves 64 lanes x 16 B = RPI rows.
-// idxv: lane l holds the index of chunk row l (< 0 -> the row is zeros).
-// BUF = true : the matrix is < 4 GiB and addressed through a buffer descriptor (32-bit offsets, zeros
-//              from the hardware range check) -- ~1/3 of the VALU work per DMA of the pointer form;
+// idxv: lane l holds the index of chunk row l; padding slots carry index == n_rows (one past the end).
+// BUF = true : the matrix has < 2^24 rows and < 4 GiB and is addressed through a buffer descriptor:
+//              offset = idx * row_bytes + column offset is ONE v_mad_u32_u24, and a padding row is out of
+//              range by construction, so the hardware range check feeds its zeros with no select at all;
 // BUF = false: 64-bit pointers, zeros from a 16-byte zero constant.
+// The swizzled column offset of a lane depends on (row & 15) only, i.e. on (DMA index mod V): V lane-constant
+// offsets are computed once per kernel, not per DMA.
 template <int W, int MODE, bool BUF>
-__device__ __forceinline__ void issue_rows(const float* __restrict__ base, unsigned bytes, int ld, int n4, int idxv,
-                                           float* slot_base, int lane) {
-    constexpr int LPR = W / 4;       // 16-byte lanes per row
-    constexpr int RPI = 64 / LPR;    // rows per DMA instruction
-    constexpr int NOPS = 64 / RPI;   // DMA instructions per chunk
-    const int rsub = lane / LPR;
-    const int p = lane % LPR;
-    // all cross-lane index fetches first (one LDS-crossbar round trip for the batch, not one per DMA)
-    int idx[NOPS];
+struct RowGather {
+    static constexpr int LPR = W / 4;       // 16-byte lanes per row
+    static constexpr int RPI = 64 / LPR;    // rows per DMA instruction
+    static constexpr int NOPS = 64 / RPI;   // DMA instructions per chunk
+    static constexpr int V = RPI >= 16 ? 1 : 16 / RPI;
+    unsigned coff[V];   // byte offset of the 16-B column chunk this lane fetches (0xFFFFFFF0: beyond the width)
+    int rsub;
+
+    __device__ __forceinline__ void init(int lane, int n4) {
+        rsub = lane / LPR;
+        const int p = lane % LPR;
 #pragma unroll
-    for (int i = 0; i < NOPS; ++i) idx[i] = __shfl(idxv, i * RPI + rsub);
-    if constexpr (BUF) {
-        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
-#pragma unroll
-        for (int i = 0; i < NOPS; ++i) {
-            const int row = i * RPI + rsub;               // row inside the chunk
-            const int c = p ^ swizzle<MODE, LPR>(row);    // which 16-B column chunk lands at position p
-            const unsigned off = (idx[i] >= 0 && c < n4) ? (unsigned)idx[i] * (unsigned)(ld * 4) + c * 16 : 0xFFFFFFF0u;
-            dma16_buf(rsrc, off, slot_base + i * RPI * W);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NOPS; ++i) {
-            const int row = i * RPI + rsub;
-            const int c = p ^ swizzle<MODE, LPR>(row);
-            const float* gp = (idx[i] >= 0 && c < n4) ? base + (size_t)idx[i] * ld + c * 4 : g_zero16;
-            dma16(gp, slot_base + i * RPI * W);
+        for (int v = 0; v < V; ++v) {
+            const int c = p ^ swizzle<MODE, LPR>(v * RPI + rsub);   // which 16-B column chunk lands at position p
+            coff[v] = c < n4 ? (unsigned)c * 16u : 0xFFFFFFF0u;
         }
     }
-}
+
+    __device__ __forceinline__ void issue(const float* __restrict__ base, unsigned bytes, int n_rows, int ld,
+                                          int idxv, float* slot_base) const {
+        // all cross-lane index fetches first (one LDS-crossbar round trip for the batch, not one per DMA)
+        int idx[NOPS];
+#pragma unroll
+        for (int i = 0; i < NOPS; ++i) idx[i] = __shfl(idxv, i * RPI + rsub);
+        if constexpr (BUF) {
+            const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
+            const unsigned row_bytes = (unsigned)ld * 4u;
+#pragma unroll
+            for (int i = 0; i < NOPS; ++i) {
+                const unsigned co = coff[i % V];
+                const unsigned off = co == 0xFFFFFFF0u ? co : __umul24((unsigned)idx[i], row_bytes) + co;
+                dma16_buf(rsrc, off, slot_base + i * RPI * W);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NOPS; ++i) {
+                const unsigned co = coff[i % V];
+                const float* gp = (idx[i] < n_rows && co != 0xFFFFFFF0u)
+                                      ? (const float*)((const char*)(base + (size_t)idx[i] * ld) + co) : g_zero16;
+                dma16(gp, slot_base + i * RPI * W);
+            }
+        }
+    }
+};
 
 // KT x 16 B per lane of one column slice's B fragments (consecutive j are 1 KiB apart)
 template <int KT>
@@ -156,7 +173,8 @@ struct TileArgs {
     const float* wp;
     const float* bias;
     float* out;
-    unsigned x_bytes;  // rows * ldx * 4 when that fits 32 bits (buffer-descriptor gathers), else 0
+    unsigned x_bytes;  // rows * ldx * 4 when buffer-descriptor gathers are possible, else 0
+    int n_rows;        // rows of x (padding slots carry this index)
     int ldx, din4, dout, ldo, tile, n_owned;
     int dbg;  // diagnostic ablations (RGCN_DEBUG_MODE env): 1 skip MFMA+accumulate, 2 skip DMA, 4 skip B loads
 };
@@ -422,6 +440,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         // ---- producers: LDS-DMA gather, D chunks ahead of the consumers; wave (k % 4) owns chunk k ----
         const int pw = wave;
         int knext = pw;                                   // this wave's next chunk
+        RowGather<KP, kRowRead, BUF> gather;
+        gather.init(lane, (a.dbg & 2) ? 0 : a.din4);
         // Row indices of this wave's NEXT chunk: one coalesced load, issued right after the current
         // chunk's DMAs and not touched until the wave's next turn 4 iterations later (any use here would
         // make hipcc wait vmcnt(0) on the spot, i.e. for the DMAs just issued).  The address is clamped
@@ -433,8 +453,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         int idxv = load_idx(knext);
         auto issue = [&](int k) {                         // k == knext
             const int chunk = c0 + k, buf = k % NBUF;
-            issue_rows<KP, kRowRead, BUF>(a.x, a.x_bytes, a.ldx, (a.dbg & 2) ? 0 : a.din4, idxv,
-                                          ring + buf * kChunk * KP, lane);
+            gather.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idxv, ring + buf * kChunk * KP);
             dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
             dma4(a.slot_acc + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
             knext += kProducerWaves;
@@ -499,6 +518,7 @@ struct DwArgs {
     const float* x;
     const float* g;
     unsigned x_bytes, g_bytes;
+    int n_rows, n_owned;  // rows of x / of g (padding slots gather the row one past the end)
     float* slabs;      // [nblocks + R' + 1][KP*NP]
     float* bias_slabs; // [nblocks][NP]
     int ldx, din4, ldg, dout4, tile, n_chunks, num_rel;
@@ -568,12 +588,25 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     // separate role loops, consumers first in program order (see rgcn_tile_kernel)
     if (wave >= kProducerWaves) {
         zero_acc();
+        // chunk metadata one iteration ahead (three dependent scalar loads per chunk otherwise)
+        int chunk_pre = ldc(a.rel_order, i0);
+        int cnt_pre = ldc(a.chunk_cnt, chunk_pre);
+        int relv_pre = ldc(a.chunk_rel, chunk_pre);
         wg_barrier();
+#ifdef RGCN_STAMPS
+        unsigned long long st_scal = 0, st_comp = 0, st_bar = 0;
+#endif
         for (int it = 0; it < nch; ++it) {
-            const int chunk = ldc(a.rel_order, i0 + it);
+            STAMP(t0);
             const int buf = it % NBUF;
-            const int cnt = ldc(a.chunk_cnt, chunk);
-            const int rel = ldc(a.chunk_rel, chunk);
+            const int cnt = cnt_pre;
+            const int rel = relv_pre;
+            if (it + 1 < nch) {
+                chunk_pre = ldc(a.rel_order, i0 + it + 1);
+                cnt_pre = ldc(a.chunk_cnt, chunk_pre);
+                relv_pre = ldc(a.chunk_rel, chunk_pre);
+            }
+            STAMP(t1);
             if (rel != rel_cur) {
                 if (rel_cur >= 0) flush();
                 zero_acc();
@@ -644,8 +677,19 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
                     }
                 }
             }
+            STAMP(t2);
             wg_barrier();
+            STAMP(t3);
+            STAMP_ADD(st_scal, t0, t1);
+            STAMP_ADD(st_comp, t1, t2);
+            STAMP_ADD(st_bar, t2, t3);
         }
+#ifdef RGCN_STAMPS
+        if (g_stamps && cwv == 0 && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            o[0] = st_scal; o[1] = st_comp; o[2] = 0; o[3] = st_bar;
+        }
+#endif
         if (rel_cur >= 0) flush();
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
@@ -653,7 +697,11 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         // producers: wave (k % 4) owns chunk k of this workgroup's range (see rgcn_tile_kernel)
         const int pw = wave;
         int knext = pw;
-        int idx_h = -1, idx_g = -1;
+        int idx_h = 0, idx_g = 0;
+        RowGather<KP, kColRead, BUF> gather_h;
+        RowGather<NP, kColRead, BUF> gather_g;
+        gather_h.init(lane, a.din4);
+        gather_g.init(lane, a.dout4);
         // raw index loads for the wave's next chunk; combined into row ids only at its next turn
         auto load_idx = [&](int k) {
             const int kk = k < nch ? k : nch - 1;
@@ -664,9 +712,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         load_idx(knext);
         auto issue = [&](int k) {
             const int chunk = ldc(a.rel_order, i0 + k), buf = k % NBUF;
-            const int gi = idx_h >= 0 ? ldc(a.chunk_tile, chunk) * a.tile + idx_g : -1;
-            issue_rows<KP, kColRead, BUF>(a.x, a.x_bytes, a.ldx, a.din4, idx_h, ringh + buf * kChunk * KP, lane);
-            issue_rows<NP, kColRead, BUF>(a.g, a.g_bytes, a.ldg, a.dout4, gi, ringg + buf * kChunk * NP, lane);
+            const int gi = idx_h < a.n_rows ? ldc(a.chunk_tile, chunk) * a.tile + idx_g : a.n_owned;
+            gather_h.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idx_h, ringh + buf * kChunk * KP);
+            gather_g.issue(a.g, a.g_bytes, a.n_owned, a.ldg, gi, ringg + buf * kChunk * NP);
             dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
             knext += kProducerWaves;
             load_idx(knext);
@@ -676,13 +724,30 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
             if (k % kProducerWaves == pw && k < nch) issue(k);
         if (pw == 0) wait_vmcnt<0>();
         wg_barrier();
+#ifdef RGCN_STAMPS
+        unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
+#endif
         for (int it = 0; it < nch; ++it) {
             const int ki = it + D, kw = it + 1;
+            STAMP(p0);
             if (ki % kProducerWaves == pw && ki < nch) issue(ki);
+            STAMP(p1);
             if (kw % kProducerWaves == pw && kw < nch) wait_vmcnt<0>();
+            STAMP(p2);
             wg_barrier();
+            STAMP(p3);
+            STAMP_ADD(sp_issue, p0, p1);
+            STAMP_ADD(sp_wait, p1, p2);
+            STAMP_ADD(sp_bar, p2, p3);
         }
         wait_vmcnt<0>();
+#ifdef RGCN_STAMPS
+        if (g_stamps && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
+            if (pw == 1) o[7] = nch;
+        }
+#endif
     }
 }
 
@@ -753,9 +818,14 @@ static int check_plan(const rgcn_plan_t* p) {
     return RGCN_OK;
 }
 
-// bytes if the matrix can be addressed with 32-bit buffer offsets (the all-ones region is reserved for
-// the out-of-range "zeros" offset), else 0 -> the kernels fall back to 64-bit pointers
-static unsigned fits_u32(size_t bytes) { return bytes < 0xFFFFFF00ull ? (unsigned)bytes : 0u; }
+// bytes of a [rows, ld] fp32 matrix if it can be gathered through a buffer descriptor: 24-bit row index and
+// row size (v_mad_u32_u24), 32-bit offsets with the one-past-the-end padding row and the all-ones "beyond
+// the width" offset out of range; else 0 -> the kernels fall back to 64-bit pointers
+static unsigned buffer_bytes(int rows, int ld) {
+    const size_t bytes = (size_t)rows * ld * sizeof(float);
+    const size_t with_pad_row = bytes + (size_t)ld * sizeof(float);
+    return (rows < (1 << 24) && with_pad_row < 0xFFFFFF00ull) ? (unsigned)bytes : 0u;
+}
 
 static int check_stride(int ld, int width) {
     if (width < 1 || width > RGCN_MAX_WIDTH) return RGCN_ERR_WIDTH;
@@ -816,7 +886,8 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.bias = bias;
     a.out = out;
     a.ldx = ldx;
-    a.x_bytes = fits_u32((size_t)plan->n_nodes * ldx * sizeof(float));
+    a.x_bytes = buffer_bytes(plan->n_nodes, ldx);
+    a.n_rows = plan->n_nodes;
     a.din4 = (kin + 3) / 4;
     a.dout = nout;
     a.ldo = ldo;
@@ -958,8 +1029,10 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.slabs = (float*)workspace;
     a.bias_slabs = a.slabs + dw_slab_floats(plan->num_relations, KP, NP);
     a.ldx = ldx;
-    a.x_bytes = fits_u32((size_t)plan->n_nodes * ldx * sizeof(float));
-    a.g_bytes = fits_u32((size_t)plan->n_owned * ldg * sizeof(float));
+    a.x_bytes = buffer_bytes(plan->n_nodes, ldx);
+    a.g_bytes = buffer_bytes(plan->n_owned, ldg);
+    a.n_rows = plan->n_nodes;
+    a.n_owned = plan->n_owned;
     a.din4 = (din + 3) / 4;
     a.ldg = ldg;
     a.dout4 = (dout + 3) / 4;

@@ -14,7 +14,8 @@ Layout (all int32 / float32, device resident):
   into CHUNKS of ``CHUNK`` = 64 edge slots (the last one padded), so a chunk is
   relation-homogeneous (one MFMA B operand) and exactly one LDS-DMA ring slot;
 * the self-loop (PyG ``root``) is relation id ``num_relations`` with one pseudo edge per node;
-* per slot: ``slot_src`` (row to gather, -1 = padding), ``slot_w`` (edge weight
+* per slot: ``slot_src`` (row to gather; padding = ``n_nodes``, one past the last row, which a buffer-descriptor
+  gather turns into zeros by its range check), ``slot_w`` (edge weight
   ``1 / max(1, c[dst, rel])`` for ``aggr='mean'``, 0 = padding), ``slot_dstl`` (row inside the tile,
   ``tile`` = padding: the kernels keep one dummy accumulator row there); inside a chunk the slots are
   sorted by ``slot_dstl``, which the forward kernel's run-sum relies on; ``slot_acc`` packs what that
@@ -149,7 +150,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     rank = torch.arange(key.shape[0], device=dev) - gstart[grp_of_edge]
     slot = chunk_base[grp_of_edge] * CHUNK + rank
     n_slots = n_chunks * CHUNK
-    slot_src = torch.full((n_slots,), -1, dtype=torch.int32, device=dev)
+    slot_src = torch.full((n_slots,), n_nodes, dtype=torch.int32, device=dev)  # padding: one past the last row
     slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
     slot_dstl = torch.full((n_slots,), tile, dtype=torch.int32, device=dev)  # padding -> dummy accumulator row
     slot_src[slot] = g_all.to(torch.int32)

@@ -14,7 +14,7 @@ def _slots(plan):
     dstl = plan.slot_dstl.cpu().numpy().astype(np.int64)
     rel = np.repeat(plan.chunk_rel.cpu().numpy().astype(np.int64), CHUNK)
     tile = np.repeat(plan.chunk_tile.cpu().numpy().astype(np.int64), CHUNK)
-    valid = src >= 0
+    valid = src < plan.n_nodes
     node = tile * plan.tile + dstl  # local to node_begin
     return src, w, rel, node, valid
 

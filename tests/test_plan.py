@@ -26,7 +26,8 @@ def _check_invariants(plan, n_real_edges):
     src = plan.slot_src.view(-1, c)
     cnt = plan.chunk_cnt.long()
     col = torch.arange(c)[None, :]
-    assert torch.all((src >= 0) == (col < cnt[:, None]))          # valid slots are a prefix
+    assert torch.all((src < plan.n_nodes) == (col < cnt[:, None]))  # valid slots are a prefix
+    assert torch.all(src[col >= cnt[:, None]] == plan.n_nodes)
     assert torch.all(plan.slot_w.view(-1, c)[col >= cnt[:, None]] == 0)
     assert int(cnt.sum()) == n_real_edges + plan.n_owned            # + one root pseudo edge per node
     dl = plan.slot_dstl.view(-1, c)
@@ -116,7 +117,7 @@ def test_duplicate_triples_merge_into_one_weighted_slot():
     ei = torch.tensor([[0, 0, 1, 0], [2, 2, 2, 2]])
     et = torch.tensor([0, 0, 0, 0])
     p = P.build_graph_plans(ei, et, 3, 1, 16).fwd
-    valid = p.slot_src >= 0
+    valid = p.slot_src < p.n_nodes
     rel = torch.repeat_interleave(p.chunk_rel, P.CHUNK)
     real = valid & (rel == 0)
     assert real.sum() == 2

@@ -24,9 +24,16 @@ lib.rgcn_debug_set_stamps.argtypes = [ctypes.c_void_p]
 assert lib.rgcn_debug_set_stamps(stamps.data_ptr()) == 0
 out = torch.empty(n, 64, device=dev)
 pk = _lib.pack_weights(w, root, False)
-for _ in range(2):
-    _lib.fwd(_lib.plan_struct(fp), x, 64, pk, None, out, 64)
+which = os.environ.get("RGCN_WHICH", "fwd")
+if which == "fwd":
+    for _ in range(2):
+        _lib.fwd(_lib.plan_struct(fp), x, 64, pk, None, out, 64)
+else:
+    dwt, drt, dbt = torch.empty_like(w), torch.empty_like(root), torch.empty(64, device=dev)
+    for _ in range(2):
+        _lib.bwd_dw(_lib.plan_struct(fp), x, 64, dg, 64, dwt, drt, dbt)
 torch.cuda.synchronize()
+print("kernel:", which)
 s = stamps.cpu().numpy().reshape(-1, 8).astype(np.float64)
 nch = s[:, 7]
 tot_c = s[:, 0:4].sum(1); tot_p = s[:, 4:7].sum(1)
