@@ -134,7 +134,7 @@ def main():
         conv.root.copy_(root)
     del weight, root
     if world > 1:
-        rdist.attach(conv, n)
+        rdist.attach(conv, n, e)
     x.requires_grad_(True)
 
     torch.cuda.synchronize()

@@ -35,14 +35,16 @@ def _rows16(t: Tensor, width: int) -> Tensor:
     return t.contiguous()
 
 
-def tile_for(in_channels: int, out_channels: int) -> int:
-    """Output nodes per tile: the tile accumulator [tile, pad(width)] fp32 shares the 160 KiB LDS with
-    the DMA ring; both directions (forward: width = out, dX: width = in) use the same tile so one
-    pair of plans serves a layer."""
+def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0, num_relations: int = 1) -> int:
+    """Output nodes per tile (plan.choose_tile): bounded by the LDS budget of the wider side, tuned to the
+    graph's density so that (tile, relation) groups fill their 64-slot chunks.  ``RGCN_TILE`` overrides."""
     if not (1 <= in_channels <= 128 and 1 <= out_channels <= 128):
         raise ValueError(f"RGCNConv widths must be in 1..128, got {in_channels}->{out_channels}")
-    widest = max(in_channels, out_channels)
-    return 128 if widest > 64 else 256
+    import os
+    if "RGCN_TILE" in os.environ:
+        return int(os.environ["RGCN_TILE"])
+    from .plan import choose_tile
+    return choose_tile(n_nodes, n_edges, num_relations, in_channels, out_channels)
 
 
 class DistContext:
@@ -235,7 +237,7 @@ class RGCNConv(nn.Module):
 
     def _plans(self, x: Tensor, edge_index: Tensor, edge_type: Tensor) -> GraphPlans:
         n = x.shape[0]
-        tile = tile_for(self.in_channels, self.out_channels)
+        tile = tile_for(self.in_channels, self.out_channels, n, int(edge_type.shape[0]), self.num_relations)
         if self.dist is None:
             return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr)
         from .dist import cached_rank_plans

@@ -86,10 +86,12 @@ __device__ __forceinline__ int pick16(int idx, int4 q0, int4 q1, int4 q2, int4 q
 // on the read; the LDS image itself stays lane-linear as LDS-DMA requires).
 //   kRowRead  : rows are read 16 at a time with ds_read_b128 (A operand of H @ W)        -> f(r) = r
 //   kColRead  : 4 consecutive rows are read per ds_read_b32 (both operands of H^T @ G)   -> f(r) = rot2(r)
-enum SwizzleMode { kRowRead = 0, kColRead = 1 };
+//   kLinear   : no swizzle (whole rows read by 16 consecutive lanes with ds_read_b128: conflict free as is)
+enum SwizzleMode { kRowRead = 0, kColRead = 1, kLinear = 2 };
 template <int MODE, int LPR>
 __device__ __forceinline__ int swizzle(int row) {
     constexpr int mask = (LPR - 1) < 15 ? (LPR - 1) : 15;
+    if (MODE == kLinear) return 0;
     if (MODE == kRowRead) return row & mask;
     return (((row & 3) << 2) | ((row >> 2) & 3)) & mask;
 }

@@ -507,6 +507,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
 // ------------------------------------------------------------------------------------------------
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
+constexpr int kDwSlabsPer = 4;  // partial slabs per (workgroup, relation): one per consumer wave in the wide kernel
+
 struct DwArgs {
     const int* rel_order;
     const int* chunk_rel;
@@ -519,8 +521,8 @@ struct DwArgs {
     const float* g;
     unsigned x_bytes, g_bytes;
     int n_rows, n_owned;  // rows of x / of g (padding slots gather the row one past the end)
-    float* slabs;      // [nblocks + R' + 1][KP*NP]
-    float* bias_slabs; // [nblocks][NP]
+    float* slabs;      // [(nblocks + R' + 1) * 4][KP*NP]
+    float* bias_slabs; // [nblocks * 4][NP]
     int ldx, din4, ldg, dout4, tile, n_chunks, num_rel;
 };
 
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         }
     };
     auto flush = [&]() {
-        float* slab = a.slabs + (size_t)(b + rel_cur) * (KP * NP);
+        float* slab = a.slabs + (size_t)(b + rel_cur) * kDwSlabsPer * (KP * NP);   // sub-slab 0 of 4
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
             const int nt = ntb + 4 * s;
@@ -580,7 +582,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
                 float v = bsum[s];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (kq == 0) a.bias_slabs[(size_t)b * NP + 16 * nt + rowl] = v;
+                if (kq == 0) a.bias_slabs[(size_t)b * kDwSlabsPer * NP + 16 * nt + rowl] = v;
             }
         }
     };
@@ -751,6 +753,220 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel, wide form (KP, NP multiples of 64)
+// ------------------------------------------------------------------------------------------------
+// Same producers / ring / walk as rgcn_dw_kernel, different consumer decomposition.  There each consumer
+// wave owns 16 output columns and reads its MFMA operands element-wise (ds_read_b32 with a swizzled address
+// per element: 6 LDS reads + their address arithmetic per 4 MFMAs, and fp32 MFMAs share the SIMD pipe with
+// that arithmetic).  Here a wave owns the WHOLE [KP x NP] accumulator and a quarter of the rows:
+//   lane (ml = l & 15, kq = l >> 4) reads H[row][64u + 4 ml .. +3] and G[row][64u + 4 ml .. +3] with ONE
+//   ds_read_b128 each; component j of the first is the A operand and component j' of the second the B operand
+//   of the MFMA whose 16 x 16 output tile is { dW[64u + 4 m' + j][64u' + 4 n' + j'] } -- a strided set of rows
+//   and columns, which an outer-product accumulation does not care about.
+// 3 LDS reads per 16 (KP = NP = 64) MFMAs.  The four waves' partial sums go to four sub-slabs.
+template <int KP, int NP, int NBUF, bool BUF>
+__global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs a) {
+    constexpr int UA = KP / 64, UB = NP / 64;
+    constexpr int NA = 4 * UA, NB = 4 * UB;
+    constexpr int D = NBUF - 1;
+    static_assert(D >= 1 && D <= kProducerWaves, "one chunk in flight per producer wave");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ringh = lds;                                   // [NBUF][64][KP]
+    float* ringg = ringh + NBUF * kChunk * KP;            // [NBUF][64][NP]
+    float* wring = ringg + NBUF * kChunk * NP;            // [NBUF][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int i0 = (int)((long)b * a.n_chunks / nb);
+    const int i1 = (int)((long)(b + 1) * a.n_chunks / nb);
+    const int nch = i1 - i0;
+    if (nch <= 0) return;
+
+    if (wave >= kProducerWaves) {
+        const int cw = wave - kProducerWaves;
+        const int ml = lane & 15, kq = lane >> 4;
+        f32x4 acc[NA][NB];
+        float bsum[NB];
+        int rel_cur = -1;
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+                bsum[jb] = 0.f;
+#pragma unroll
+                for (int ia = 0; ia < NA; ++ia) acc[ia][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto flush = [&]() {
+            float* slab = a.slabs + ((size_t)(b + rel_cur) * kDwSlabsPer + cw) * (KP * NP);
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int colh = 64 * (ia >> 2) + 4 * (4 * kq + r) + (ia & 3);
+                        const int colg = 64 * (jb >> 2) + 4 * ml + (jb & 3);
+                        slab[colh * NP + colg] = acc[ia][jb][r];
+                    }
+            if (rel_cur == a.num_rel) {
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) {
+                    float v = bsum[jb];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (kq == 0)
+                        a.bias_slabs[((size_t)b * kDwSlabsPer + cw) * NP + 64 * (jb >> 2) + 4 * ml + (jb & 3)] = v;
+                }
+            }
+        };
+        zero_acc();
+        int chunk_pre = ldc(a.rel_order, i0);
+        int cnt_pre = ldc(a.chunk_cnt, chunk_pre);
+        int relv_pre = ldc(a.chunk_rel, chunk_pre);
+        wg_barrier();
+#ifdef RGCN_STAMPS
+        unsigned long long st_scal = 0, st_comp = 0, st_bar = 0;
+#endif
+        for (int it = 0; it < nch; ++it) {
+            STAMP(t0);
+            const int buf = it % NBUF;
+            const int cnt = cnt_pre;
+            const int rel = relv_pre;
+            if (it + 1 < nch) {
+                chunk_pre = ldc(a.rel_order, i0 + it + 1);
+                cnt_pre = ldc(a.chunk_cnt, chunk_pre);
+                relv_pre = ldc(a.chunk_rel, chunk_pre);
+            }
+            STAMP(t1);
+            if (rel != rel_cur) {
+                if (rel_cur >= 0) flush();
+                zero_acc();
+                rel_cur = rel;
+            }
+            const bool is_root = rel == a.num_rel;
+            const float* hb = ringh + buf * kChunk * KP + 4 * ml;
+            const float* gb = ringg + buf * kChunk * NP + 4 * ml;
+            const float* wb = wring + buf * kChunk;
+            // group g = rows 16g .. 16g+15; this wave takes rows 16g + 4cw + kq (one MFMA k-step per group).
+            // Rows beyond cnt were DMA'd as zeros (w = 0 too): no masking.
+            struct Grp {
+                f32x4 a4[UA];
+                f32x4 g4[UB];
+                float wv;
+            };
+            auto load_grp = [&](Grp& o, int g) {
+                const int row = 16 * g + 4 * cw + kq;
+                o.wv = wb[row];
+#pragma unroll
+                for (int u = 0; u < UA; ++u) o.a4[u] = *(const f32x4*)(hb + row * KP + 64 * u);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) o.g4[u] = *(const f32x4*)(gb + row * NP + 64 * u);
+            };
+            auto compute_grp = [&](const Grp& o) {
+                float bv[NB];
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) {
+                    const float gv = o.g4[jb >> 2][jb & 3];
+                    if (is_root) bsum[jb] += gv;
+                    bv[jb] = gv * o.wv;
+                }
+#pragma unroll
+                for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+                    for (int jb = 0; jb < NB; ++jb)
+                        acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a4[ia >> 2][ia & 3], bv[jb], acc[ia][jb], 0, 0, 0);
+            };
+            const int ngrp = (cnt + 15) >> 4;
+            Grp grp[2];
+            load_grp(grp[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gi = 0; gi < kChunk / 16; ++gi) {
+                if (gi < ngrp) {
+                    if (gi + 1 < ngrp) {
+                        load_grp(grp[(gi + 1) & 1], gi + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    compute_grp(grp[gi & 1]);
+                }
+            }
+            STAMP(t2);
+            wg_barrier();
+            STAMP(t3);
+            STAMP_ADD(st_scal, t0, t1);
+            STAMP_ADD(st_comp, t1, t2);
+            STAMP_ADD(st_bar, t2, t3);
+        }
+#ifdef RGCN_STAMPS
+        if (g_stamps && cw == 0 && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            o[0] = st_scal; o[1] = st_comp; o[2] = 0; o[3] = st_bar;
+        }
+#endif
+        if (rel_cur >= 0) flush();
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
+    }
+    if (wave < kProducerWaves) {
+        // producers: wave (k % 4) owns chunk k of this workgroup's range (see rgcn_tile_kernel)
+        const int pw = wave;
+        int knext = pw;
+        int idx_h = 0, idx_g = 0;
+        RowGather<KP, kLinear, BUF> gather_h;
+        RowGather<NP, kLinear, BUF> gather_g;
+        gather_h.init(lane, a.din4);
+        gather_g.init(lane, a.dout4);
+        auto load_idx = [&](int k) {
+            const int kk = k < nch ? k : nch - 1;
+            const int chunk = ldc(a.rel_order, i0 + kk);
+            idx_h = a.slot_src[(size_t)chunk * kChunk + lane];
+            idx_g = a.slot_dstl[(size_t)chunk * kChunk + lane];
+        };
+        load_idx(knext);
+        auto issue = [&](int k) {
+            const int chunk = ldc(a.rel_order, i0 + k), buf = k % NBUF;
+            const int gi = idx_h < a.n_rows ? ldc(a.chunk_tile, chunk) * a.tile + idx_g : a.n_owned;
+            gather_h.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idx_h, ringh + buf * kChunk * KP);
+            gather_g.issue(a.g, a.g_bytes, a.n_owned, a.ldg, gi, ringg + buf * kChunk * NP);
+            dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
+            knext += kProducerWaves;
+            load_idx(knext);
+        };
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (k % kProducerWaves == pw && k < nch) issue(k);
+        if (pw == 0) wait_vmcnt<0>();
+        wg_barrier();
+#ifdef RGCN_STAMPS
+        unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
+#endif
+        for (int it = 0; it < nch; ++it) {
+            const int ki = it + D, kw = it + 1;
+            STAMP(p0);
+            if (ki % kProducerWaves == pw && ki < nch) issue(ki);
+            STAMP(p1);
+            if (kw % kProducerWaves == pw && kw < nch) wait_vmcnt<0>();
+            STAMP(p2);
+            wg_barrier();
+            STAMP(p3);
+            STAMP_ADD(sp_issue, p0, p1);
+            STAMP_ADD(sp_wait, p1, p2);
+            STAMP_ADD(sp_bar, p2, p3);
+        }
+        wait_vmcnt<0>();
+#ifdef RGCN_STAMPS
+        if (g_stamps && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
+            if (pw == 1) o[7] = nch;
+        }
+#endif
+    }
+}
+
 // slabs -> gradients, fixed summation order (block index ascending) => bitwise reproducible.
 // grid = (R' + 2, parts): blockIdx.x = relation (R' = root, R'+1 = bias), blockIdx.y = slice of the elements.
 // The workgroups whose chunk range touches relation r are a contiguous run [b_lo, b_hi].
@@ -764,7 +980,7 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
         if (d_bias == nullptr || blockIdx.y != 0) return;
         for (int n = threadIdx.x; n < dout; n += blockDim.x) {
             float s = 0.f;
-            for (int b = 0; b < nblocks; ++b) s += bias_slabs[(size_t)b * NP + n];
+            for (int b = 0; b < nblocks * kDwSlabsPer; ++b) s += bias_slabs[(size_t)b * NP + n];
             d_bias[n] = s;
         }
         return;
@@ -792,7 +1008,9 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
     for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < din * dout; e += gridDim.y * blockDim.x) {
         const int k = e / dout, n = e - k * dout;
         float s = 0.f;
-        for (int b = lo; b <= hi; ++b) s += slabs[(size_t)(b + r) * KP * NP + (size_t)k * NP + n];
+        for (int b = lo; b <= hi; ++b)
+            for (int c = 0; c < kDwSlabsPer; ++c)
+                s += slabs[((size_t)(b + r) * kDwSlabsPer + c) * KP * NP + (size_t)k * NP + n];
         dst[e] = s;
     }
 }
@@ -833,16 +1051,25 @@ static int check_stride(int ld, int width) {
     return RGCN_OK;
 }
 
-template <int KP, int NP>
-static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
-    constexpr int NBUF = tile_nbuf<KP>();
-    const size_t lds = sizeof(float) * ((size_t)(a.tile + 1) * NP + (size_t)NBUF * kChunk * (KP + 2));
-    if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
+template <int KP, int NP, int NBUF>
+static int launch_tile_nbuf(const TileArgs& a, int n_tiles, size_t lds, hipStream_t stream) {
     auto kern = a.x_bytes ? rgcn_tile_kernel<KP, NP, NBUF, true> : rgcn_tile_kernel<KP, NP, NBUF, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kThreads), lds, stream, a);
     return (int)hipGetLastError();
+}
+
+// deepest DMA ring (4, 3 or 2 slots) that fits beside the tile accumulator in the 160 KiB LDS
+template <int KP, int NP>
+static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
+    auto bytes = [&](int nbuf) {
+        return sizeof(float) * ((size_t)(a.tile + 1) * NP + (size_t)nbuf * kChunk * (KP + 2));
+    };
+    if (KP < 128 && bytes(4) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 4>(a, n_tiles, bytes(4), stream);
+    if (KP < 128 && bytes(3) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 3>(a, n_tiles, bytes(3), stream);
+    if (bytes(2) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 2>(a, n_tiles, bytes(2), stream);
+    return RGCN_ERR_LDS;
 }
 
 template <int KP>
@@ -903,7 +1130,11 @@ static int launch_dw(const DwArgs& a, int nblocks, hipStream_t stream) {
     constexpr int NBUF = dw_nbuf<KP, NP>();
     const size_t lds = sizeof(float) * ((size_t)NBUF * kChunk * (KP + NP + 1));
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
-    auto kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_kernel<KP, NP, NBUF, true> : rgcn_dw_kernel<KP, NP, NBUF, false>;
+    void (*kern)(const DwArgs);
+    if constexpr (KP % 64 == 0 && NP % 64 == 0 && KP * NP <= 64 * 128)
+        kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_wide_kernel<KP, NP, NBUF, true> : rgcn_dw_wide_kernel<KP, NP, NBUF, false>;
+    else
+        kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_kernel<KP, NP, NBUF, true> : rgcn_dw_kernel<KP, NP, NBUF, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kThreads), lds, stream, a);
@@ -931,7 +1162,9 @@ static int dispatch_dw(int KP, int NP, const DwArgs& a, int nb, hipStream_t s) {
     return RGCN_ERR_WIDTH;
 }
 
-static size_t dw_slab_floats(int num_rel, int KP, int NP) { return (size_t)(kDwBlocks + num_rel + 1) * KP * NP; }
+static size_t dw_slab_floats(int num_rel, int KP, int NP) {
+    return (size_t)(kDwBlocks + num_rel + 1) * kDwSlabsPer * KP * NP;
+}
 
 }  // namespace rgcn
 
@@ -999,7 +1232,7 @@ extern "C" size_t rgcn_bwd_dw_workspace_bytes(const rgcn_plan_t* plan, int din, 
     if (plan == nullptr) return 0;
     const int KP = padded_width(din), NP = padded_width(dout);
     if (KP == 0 || NP == 0) return 0;
-    return sizeof(float) * (dw_slab_floats(plan->num_relations, KP, NP) + (size_t)kDwBlocks * NP);
+    return sizeof(float) * (dw_slab_floats(plan->num_relations, KP, NP) + (size_t)kDwBlocks * kDwSlabsPer * NP);
 }
 
 extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* g, int ldg,

@@ -54,9 +54,12 @@ def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr,
         extra_key=("rank", dctx.rank, dctx.world))
 
 
-def attach(module: torch.nn.Module, n_nodes: int, group=None) -> None:
-    """Switch every RGCNConv under ``module`` to the edge-partitioned path for the current process group."""
+def attach(module: torch.nn.Module, n_nodes: int, n_edges: int, group=None) -> None:
+    """Switch every RGCNConv under ``module`` to the edge-partitioned path for the current process group
+    (``n_nodes`` / ``n_edges`` of the graph the module will see: they fix the tile size and with it the
+    tile-aligned node ranges)."""
     from .conv import tile_for
     for m in module.modules():
         if isinstance(m, RGCNConv):
-            m.dist = make_context(n_nodes, tile_for(m.in_channels, m.out_channels), group)
+            tile = tile_for(m.in_channels, m.out_channels, n_nodes, n_edges, m.num_relations)
+            m.dist = make_context(n_nodes, tile, group)

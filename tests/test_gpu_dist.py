@@ -46,7 +46,7 @@ def _worker(rank, world, port, ret):
             conv.root.copy_(root)
             conv.bias.copy_(bias + 0.25)
         if partitioned:
-            rdist.attach(conv, n)
+            rdist.attach(conv, n, e)
             assert conv.dist is not None and conv.dist.world == world
         xd = x.to(dev).requires_grad_(True)
         out = conv(xd, ei.to(dev), et.to(dev))

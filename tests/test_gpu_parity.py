@@ -24,7 +24,7 @@ def _abi_layer(dev, ei, et, n, num_rel, x, w_full, root, bias, dout_grad, tile=N
     from scaling_rgcn_training_amd import _lib, plan as P
     from scaling_rgcn_training_amd.conv import tile_for, _rows16, _round4
     din, dout = w_full.shape[1], w_full.shape[2]
-    tile = tile or tile_for(din, dout)
+    tile = tile or tile_for(din, dout, n, int(et.shape[0]), num_rel)
     plans = P.build_graph_plans(ei.to(dev), et.to(dev), n, num_rel, tile, aggr)
     xd = _rows16(x.to(dev), din)
     gd = _rows16(dout_grad.to(dev), dout)

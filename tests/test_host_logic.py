@@ -85,3 +85,15 @@ def test_rank_ranges_tile_aligned_and_cover():
             assert b % tile == 0 or b == n
             covered += e - b
         assert covered == n
+
+
+def test_choose_tile_respects_lds_and_prefers_full_chunks():
+    from scaling_rgcn_training_amd.plan import CHUNK, LDS_BYTES, choose_tile, padded_width
+    for args in ((10_000_000, 100_000_000, 32, 64, 64), (8243, 49838, 89, 63, 16), (1000, 9000, 5, 128, 128),
+                 (100, 0, 3, 8, 8), (5000, 10 ** 6, 2, 64, 128)):
+        t = choose_tile(*args)
+        kp, np_ = padded_width(args[3]), padded_width(args[4])
+        assert t % 16 == 0 and t >= 64
+        assert (t + 1) * max(kp, np_) * 4 + 2 * CHUNK * (min(kp, np_) + 2) * 4 <= LDS_BYTES
+    # the headline graph: 0.3125 edges per (node, relation); 384 nodes -> groups of ~120 = two nearly full chunks
+    assert choose_tile(10_000_000, 100_000_000, 32, 64, 64) == 384

@@ -11,7 +11,7 @@ w, root, bias = O.synthetic_params(r, din, dout, seed=3)
 g = torch.Generator().manual_seed(11)
 x = torch.randn(n, din, generator=g)
 ref, _ = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy())
-tile = tile_for(din, dout)
+tile = tile_for(din, dout, n, e, r)
 plans = P.build_graph_plans(ei.to(dev), et.to(dev), n, r, tile)
 xd = _rows16(x.to(dev), din)
 out = torch.full((n, _round4(dout)), float('nan'), device=dev)
