@@ -204,10 +204,20 @@ def main():
     alg = algorithmic_bytes(e / world, n / world, r, d, d)
     tile_ms = kernel_ms["fwd"] + kernel_ms["dx"]
     if tile_ms >= kernel_ms["dw"]:
-        kname, kbytes, kms = "rgcn_tile_kernel<64,64,4> (fwd + dX launches)", (alg["fwd"] + alg["dx"]) / 2, tile_ms / 2
+        kname, kbytes, kms = "rgcn_tile_kernel<64,64,3> (fwd + dX launches)", (alg["fwd"] + alg["dx"]) / 2, tile_ms / 2
     else:
-        kname, kbytes, kms = "rgcn_dw_kernel<64,64,4>", alg["dw"], kernel_ms["dw"]
+        kname, kbytes, kms = "rgcn_dw_wide_kernel<64,64,4>", alg["dw"], kernel_ms["dw"]
     achieved = kbytes / (kms * 1e-3) / 1e9
+    # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs,
+    # gfx950 correction applied) committed under profiles/ -- only quoted for the workload they were taken on
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
+        if world == 1 and (n, e, r, d) == (10_000_000, 100_000_000, 32, 64):
+            key = "rgcn::rgcn_tile_kernel<64, 64, 3, true>" if "tile" in kname else "rgcn::rgcn_dw_wide_kernel<64, 64, 4, true>"
+            traffic = pm["kernels"][key]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
 
     if rank == 0:
         rec = {
@@ -228,7 +238,7 @@ def main():
                        "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
                        "partition": f"dst-range x{world}" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms},
             "kernel_ms": kernel_ms,
             "plan_build_s": plan_s,
