@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 2
+#define RGCN_ABI_VERSION 3
 #define RGCN_CHUNK 64 /* edge slots per chunk == rows of one LDS ring slot */
 #define RGCN_MAX_WIDTH 128
 
@@ -61,8 +61,10 @@ typedef struct rgcn_plan {
     int32_t n_chunks;
     const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
     const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */
-    const int32_t* chunk_cnt;  /* [n_chunks] valid slots (1..64), a prefix of the chunk */
+    const int32_t* chunk_cnt;  /* [n_chunks] slots of the chunk's used 16-slot MFMA row tiles (16, 32, 48 or 64);
+                                * padding slots sit at the end of every row tile */
     const int32_t* chunk_tile; /* [n_chunks] */
+    const int32_t* chunk_flags; /* [n_chunks] bit t: row tile t holds a repeated destination (needs the run-sum) */
     const int32_t* rel_order;  /* [n_chunks] chunk ids sorted by (relation, tile) */
     const int32_t* slot_src;   /* [n_chunks * 64] row to gather; padding = n_nodes (one past the last row) */
     const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */

@@ -166,6 +166,7 @@ struct TileArgs {
     const int* tile_ptr;
     const int* chunk_rel;
     const int* chunk_cnt;
+    const int* chunk_flags;
     const int* slot_src;
     const float* slot_w;
     const int* slot_acc;
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         // in front of the loop's MFMAs, and those s_waitcnt vmcnt(N) would also wait for the asm prefetch
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         int cnt_pre = ldc(a.chunk_cnt, c0);
+        int flags_pre = ldc(a.chunk_flags, c0);
         int rel_pre = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
         wg_barrier();
 #ifdef RGCN_STAMPS
@@ -249,8 +251,12 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             const int buf = it % NBUF;
             // chunk metadata arrives one iteration ahead (scalar loads issued a whole chunk earlier)
             const int cnt = cnt_pre;
+            const int flags = flags_pre;
             const int rel_next = rel_pre;
-            if (it + 1 < nch) cnt_pre = ldc(a.chunk_cnt, chunk + 1);
+            if (it + 1 < nch) {
+                cnt_pre = ldc(a.chunk_cnt, chunk + 1);
+                flags_pre = ldc(a.chunk_flags, chunk + 1);
+            }
             if (it + 2 < nch) rel_pre = ldc(a.chunk_rel, chunk + 2);
 #ifdef RGCN_STAMPS
             asm volatile("" ::"s"(cnt), "s"(rel_next));
@@ -327,7 +333,21 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             // pairwise distinct destinations inside the tile.  Y's accumulator registers are already in
             // B-operand layout for MFMA step i with k = 4*k' + i: no data movement.  The accumulator reads
             // of stage C are issued here (after the previous tile's stage-C writes in program order).
-            auto stage_b = [&](const Ops& o, Tile& t) {
+            auto stage_b = [&](const Ops& o, Tile& t, bool dup) {
+                if (!dup) {
+                    // no destination repeats inside this row tile (the plan spreads a run over different
+                    // tiles whenever it can): every row ends its own run, P would be diag(w) -- skip the product
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t.dst[i] = out_lds + (o.d4[i] & 0xFFFF) * NP + 16 * cw + rowl;
+#pragma unroll
+                    for (int s = 0; s < SL; ++s) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t.old[s][i] = t.dst[i][16 * CW * s];
+                        t.z[s][0] = t.y[s] * o.w4;
+                        t.z[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    return;
+                }
                 float pm[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -386,7 +406,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                     }
                     if (step < NRT) stage_a(ops[step], tl[step]);
                     if (step >= 2) stage_c(tl[step - 2]);
-                    if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1]);
+                    if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1], (flags >> (step - 1)) & 1);
                 }
                 // ask the scheduler for MFMA / VALU / LDS interleaving: an MFMA holds the issue port for 8
                 // of its 32 cycles, the other 24 take ~5 single-issue instructions of the same wave
@@ -1027,7 +1047,8 @@ constexpr int dw_nbuf() { return (KP == 128 || NP == 128) ? 2 : 4; }
 
 static int check_plan(const rgcn_plan_t* p) {
     if (p == nullptr) return RGCN_ERR_NULL;
-    if (!p->tile_ptr || !p->chunk_rel || !p->chunk_cnt || !p->chunk_tile || !p->rel_order || !p->slot_src ||
+    if (!p->tile_ptr || !p->chunk_rel || !p->chunk_cnt || !p->chunk_tile || !p->chunk_flags || !p->rel_order ||
+        !p->slot_src ||
         !p->slot_w || !p->slot_dstl || !p->slot_acc)
         return RGCN_ERR_NULL;
     if (p->n_nodes <= 0 || p->n_owned <= 0 || p->num_relations <= 0 || p->tile <= 0 || (p->tile % 16) != 0 || p->tile > 32768 ||
@@ -1105,6 +1126,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.tile_ptr = plan->tile_ptr;
     a.chunk_rel = plan->chunk_rel;
     a.chunk_cnt = plan->chunk_cnt;
+    a.chunk_flags = plan->chunk_flags;
     a.slot_src = plan->slot_src;
     a.slot_w = plan->slot_w;
     a.slot_acc = plan->slot_acc;

@@ -21,7 +21,7 @@ Layout (all int32 / float32, device resident):
   sorted by ``slot_dstl``, which the forward kernel's run-sum relies on; ``slot_acc`` packs what that
   run-sum needs per slot (accumulator row | run-end position << 16, see ``run_metadata``);
   duplicate (src, dst, relation) triples share ONE slot whose weight is the sum of theirs;
-* per chunk: ``chunk_rel``, ``chunk_cnt``, ``chunk_tile``; ``tile_ptr`` gives the tile-major
+* per chunk: ``chunk_rel``, ``chunk_cnt`` (slots of the used 16-slot row tiles), ``chunk_tile``, ``chunk_flags``; ``tile_ptr`` gives the tile-major
   chunk ranges (forward / dX kernels) and ``rel_order`` the relation-major order (dW kernel).
 
 The transposed plan (``direction='bwd'``) swaps the roles of source and destination and keeps
@@ -53,6 +53,7 @@ class TilePlan:
     chunk_rel: Tensor     # int32 [n_chunks]
     chunk_cnt: Tensor     # int32 [n_chunks]
     chunk_tile: Tensor    # int32 [n_chunks]
+    chunk_flags: Tensor   # int32 [n_chunks]  bit t: MFMA row tile t of the chunk holds a repeated destination
     rel_order: Tensor     # int32 [n_chunks]
     slot_src: Tensor      # int32 [n_chunks * CHUNK]
     slot_w: Tensor        # float32 [n_chunks * CHUNK]
@@ -70,7 +71,7 @@ class TilePlan:
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (
-            self.tile_ptr, self.chunk_rel, self.chunk_cnt, self.chunk_tile, self.rel_order,
+            self.tile_ptr, self.chunk_rel, self.chunk_cnt, self.chunk_tile, self.chunk_flags, self.rel_order,
             self.slot_src, self.slot_w, self.slot_dstl, self.slot_acc))
 
 
@@ -148,7 +149,14 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     gstart = torch.cumsum(gcnt, 0) - gcnt
     grp_of_edge = torch.repeat_interleave(torch.arange(n_groups, device=dev), gcnt)
     rank = torch.arange(key.shape[0], device=dev) - gstart[grp_of_edge]
-    slot = chunk_base[grp_of_edge] * CHUNK + rank
+    # Row j of a group (sorted by destination) goes to MFMA row tile (j mod nt), position (j div nt), nt =
+    # ceil(n / 16): every tile stays sorted by destination, the tiles of a group are equally full, and a run
+    # of c equal destinations is spread over c different tiles (c <= nt), so most tiles hold pairwise distinct
+    # destinations and the forward kernel can skip its run-sum product for them (chunk_flags).
+    g16 = ROWS_PER_MFMA_TILE
+    gnt = (gcnt + (g16 - 1)) // g16
+    nt_e = gnt[grp_of_edge]
+    slot = chunk_base[grp_of_edge] * CHUNK + (rank % nt_e) * g16 + rank // nt_e
     n_slots = n_chunks * CHUNK
     slot_src = torch.full((n_slots,), n_nodes, dtype=torch.int32, device=dev)  # padding: one past the last row
     slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
@@ -156,10 +164,13 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     slot_src[slot] = g_all.to(torch.int32)
     slot_w[slot] = w_all
     slot_dstl[slot] = dstl.to(torch.int32)
-    slot_acc = run_metadata(slot_dstl, tile)
+    slot_acc, tile_dup = run_metadata(slot_dstl, tile)
+    chunk_flags = (tile_dup.view(-1, CHUNK // g16).to(torch.int32)
+                   * (2 ** torch.arange(CHUNK // g16, device=dev, dtype=torch.int32))).sum(1).to(torch.int32)
     grp_of_chunk = torch.repeat_interleave(torch.arange(n_groups, device=dev), gch)
     idx_in_grp = torch.arange(n_chunks, device=dev) - chunk_base[grp_of_chunk]
-    chunk_cnt = torch.clamp(gcnt[grp_of_chunk] - idx_in_grp * CHUNK, max=CHUNK).to(torch.int32)
+    # slots of the chunk's used row tiles (a multiple of 16; padding sits at the end of every tile)
+    chunk_cnt = (torch.clamp(gnt[grp_of_chunk] - idx_in_grp * (CHUNK // g16), max=CHUNK // g16) * g16).to(torch.int32)
     chunk_rel = (gvals[grp_of_chunk] % r1).to(torch.int32)
     chunk_tile = (gvals[grp_of_chunk] // r1).to(torch.int32)
     n_tiles = (n_own + tile - 1) // tile
@@ -172,7 +183,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     num_relations=num_relations, tile=tile, n_tiles=n_tiles, n_chunks=n_chunks,
                     n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
-                    slot_dstl=slot_dstl, slot_acc=slot_acc)
+                    slot_dstl=slot_dstl, slot_acc=slot_acc, chunk_flags=chunk_flags)
 
 
 ROWS_PER_MFMA_TILE = 16
@@ -216,13 +227,14 @@ def choose_tile(n_nodes: int, n_edges: int, num_relations: int, in_channels: int
     return best
 
 
-def run_metadata(slot_dstl: Tensor, tile: int) -> Tensor:
+def run_metadata(slot_dstl: Tensor, tile: int):
     """Per slot, for the forward kernel's run-sum (csrc/rgcn_kernels.hip stage B/C), precomputed here so
     the kernel spends no vector instructions on it: inside every 16-slot MFMA row tile, slots with equal
-    destination are adjacent (chunks are sorted by destination) and form a RUN; the run's sum is written by
-    its LAST slot only.  low 16 bits: accumulator row the slot writes (its destination if it ends a run,
-    else the dummy row ``tile``; padding slots carry destination ``tile`` already); high 16 bits: position
-    (0..15) inside the row tile of the slot that ends this slot's run."""
+    destination are adjacent (tiles are sorted by destination) and form a RUN; the run's sum is written by
+    its LAST slot only.  Returns (slot_acc, tile_dup).  slot_acc low 16 bits: accumulator row the slot writes
+    (its destination if it ends a run, else the dummy row ``tile``; padding slots carry destination ``tile``
+    already); high 16 bits: position (0..15) inside the row tile of the slot that ends this slot's run.
+    tile_dup[t]: row tile t contains a run longer than one slot (needs the run-sum product)."""
     g = ROWS_PER_MFMA_TILE
     d = slot_dstl.view(-1, g).to(torch.int64)
     nxt = torch.cat([d[:, 1:], torch.full_like(d[:, :1], -1)], dim=1)
@@ -231,7 +243,8 @@ def run_metadata(slot_dstl: Tensor, tile: int) -> Tensor:
     endpos = torch.where(is_end, pos, torch.full_like(pos, g))
     runend = torch.flip(torch.cummin(torch.flip(endpos, [1]), dim=1).values, [1])
     acc = torch.where(is_end, d, torch.full_like(d, tile))
-    return (acc | (runend << 16)).to(torch.int32).reshape(-1)
+    tile_dup = ((~is_end) & (d != tile)).any(dim=1)     # runs of padding slots do not count
+    return (acc | (runend << 16)).to(torch.int32).reshape(-1), tile_dup
 
 
 @dataclass

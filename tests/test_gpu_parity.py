@@ -104,9 +104,14 @@ def test_module_autograd_matches_golden(dev, golden):
         wf = O.effective_weight(w, comp, int(g["num_relations"]), int(g["nb"]) if mode == "block" else None,
                                 g["x"].shape[1], g["out"].shape[1])
         wf.backward(torch.from_numpy(g["d_wfull"]))
-        np.testing.assert_allclose(conv.weight.grad.cpu().numpy(), w.grad.numpy(), **TOL)
+        # condition numbers of the same chain rule: |V|, |comp| and the abs-sum of d_wfull
+        wa = torch.from_numpy(np.abs(g["weight"])).double().requires_grad_(True)
+        ca = torch.from_numpy(np.abs(g["comp"])).double().requires_grad_(True) if mode == "basis" else None
+        O.effective_weight(wa, ca, int(g["num_relations"]), int(g["nb"]) if mode == "block" else None,
+                           g["x"].shape[1], g["out"].shape[1]).backward(torch.from_numpy(c["weight"]))
+        assert_close(conv.weight.grad.cpu().numpy(), w.grad.numpy(), wa.grad.numpy(), "d_weight (decomposed)")
         if comp is not None:
-            np.testing.assert_allclose(conv.comp.grad.cpu().numpy(), comp.grad.numpy(), **TOL)
+            assert_close(conv.comp.grad.cpu().numpy(), comp.grad.numpy(), ca.grad.numpy(), "d_comp")
 
 
 WIDTHS = [(64, 64), (63, 16), (16, 5), (16, 16), (32, 64), (64, 32), (48, 100), (128, 128), (128, 16), (7, 128),

@@ -23,16 +23,25 @@ def _distinct(ei, et, n, r):
 def _check_invariants(plan, n_real_edges):
     c = P.CHUNK
     assert plan.slot_src.numel() == plan.n_chunks * c
-    src = plan.slot_src.view(-1, c)
+    src = plan.slot_src.view(-1, 16)
+    valid = src < plan.n_nodes
+    nvalid = valid.sum(1)
+    col16 = torch.arange(16)[None, :]
+    assert torch.all(valid == (col16 < nvalid[:, None]))           # valid slots are a prefix of every 16-slot row tile
+    assert torch.all(plan.slot_w.view(-1, 16)[~valid] == 0)
     cnt = plan.chunk_cnt.long()
+    assert torch.all(cnt % 16 == 0) and torch.all(cnt >= 16) and torch.all(cnt <= c)
+    used = (torch.arange(c // 16)[None, :] * 16 < cnt[:, None]).reshape(-1)   # row tiles inside chunk_cnt
+    assert torch.all(nvalid[~used] == 0) and torch.all(nvalid[used] > 0)
+    assert int(nvalid.sum()) == n_real_edges + plan.n_owned         # + one root pseudo edge per node
     col = torch.arange(c)[None, :]
-    assert torch.all((src < plan.n_nodes) == (col < cnt[:, None]))  # valid slots are a prefix
-    assert torch.all(src[col >= cnt[:, None]] == plan.n_nodes)
-    assert torch.all(plan.slot_w.view(-1, c)[col >= cnt[:, None]] == 0)
-    assert int(cnt.sum()) == n_real_edges + plan.n_owned            # + one root pseudo edge per node
-    dl = plan.slot_dstl.view(-1, c)
-    assert torch.all(dl[col < cnt[:, None]] < plan.tile) and torch.all(dl[col >= cnt[:, None]] == plan.tile)
-    assert torch.all(dl[:, 1:] >= dl[:, :-1])                      # sorted by destination inside a chunk
+    dl = plan.slot_dstl.view(-1, 16)
+    assert torch.all(dl[valid] < plan.tile) and torch.all(dl[~valid] == plan.tile)
+    assert torch.all(dl[:, 1:] >= dl[:, :-1])                      # sorted by destination inside a row tile
+    dup = torch.zeros(dl.shape[0], dtype=torch.bool)
+    dup[(valid[:, 1:] & (dl[:, 1:] == dl[:, :-1])).any(1)] = True
+    flags = ((plan.chunk_flags.long()[:, None] >> torch.arange(c // 16)[None, :]) & 1).bool().reshape(-1)
+    assert torch.equal(flags, dup)
     # run metadata: inside each 16-slot row tile, exactly the LAST slot of a run of equal destinations
     # carries that destination, all others the dummy row; every slot points at its run's last slot
     acc = (plan.slot_acc & 0xFFFF).view(-1, 16).long()
