@@ -114,6 +114,33 @@ struct RowGather {
         }
     }
 
+    // This wave's quarter (rows 16*pw .. 16*pw+15) of a chunk; row indices come from an LDS copy of the
+    // chunk's index vector (landed there by LDS-DMA iterations earlier), read with same-address broadcasts.
+    __device__ __forceinline__ void issue_quarter(const float* __restrict__ base, unsigned bytes, int n_rows, int ld,
+                                                  const int* idx_lds, float* slot_base, int pw) const {
+        constexpr int QOPS = NOPS / 4;
+        int idx[QOPS];
+#pragma unroll
+        for (int i = 0; i < QOPS; ++i) idx[i] = idx_lds[16 * pw + i * RPI + rsub];
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
+        const unsigned row_bytes = (unsigned)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < QOPS; ++i) {
+            float* dst = slot_base + (16 * pw + i * RPI) * W;
+            unsigned co;
+            if constexpr (V >= 4) co = coff[(pw * QOPS + i) % V];   // pw-dependent variant (uniform select)
+            else co = coff[i % V];
+            if constexpr (BUF) {
+                const unsigned off = co == 0xFFFFFFF0u ? co : __umul24((unsigned)idx[i], row_bytes) + co;
+                dma16_buf(rsrc, off, dst);
+            } else {
+                const float* gp = (idx[i] < n_rows && co != 0xFFFFFFF0u)
+                                      ? (const float*)((const char*)(base + (size_t)idx[i] * ld) + co) : g_zero16;
+                dma16(gp, dst);
+            }
+        }
+    }
+
     __device__ __forceinline__ void issue(const float* __restrict__ base, unsigned bytes, int n_rows, int ld,
                                           int idxv, float* slot_base) const {
         // all cross-lane index fetches first (one LDS-crossbar round trip for the batch, not one per DMA)
@@ -790,12 +817,12 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
     constexpr int UA = KP / 64, UB = NP / 64;
     constexpr int NA = 4 * UA, NB = 4 * UB;
     constexpr int D = NBUF - 1;
-    static_assert(D >= 1 && D <= kProducerWaves, "one chunk in flight per producer wave");
+    static_assert(D >= 1, "ring of at least two slots");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ringh = lds;                                   // [NBUF][64][KP]
     float* ringg = ringh + NBUF * kChunk * KP;            // [NBUF][64][NP]
-    float* wring = ringg + NBUF * kChunk * NP;            // [NBUF][64]
+    float* wring = ringg + NBUF * kChunk * NP;            // [NBUF][64]; then the index rings [2][2D+1][64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -847,7 +874,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
         int chunk_pre = ldc(a.rel_order, i0);
         int cnt_pre = ldc(a.chunk_cnt, chunk_pre);
         int relv_pre = ldc(a.chunk_rel, chunk_pre);
-        wg_barrier();
+        wg_barrier();   // producers: index vectors landed
+        wg_barrier();   // producers: chunk 0 landed
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bar = 0;
 #endif
@@ -931,44 +959,93 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
     if (wave < kProducerWaves) {
-        // producers: wave (k % 4) owns chunk k of this workgroup's range (see rgcn_tile_kernel)
+        // producers, wide kernel: EVERY producer wave issues a quarter of every chunk (rows 16*pw..+15 of the H
+        // and of the G slot), so the DMA-issue instructions are spread over the four SIMDs instead of landing
+        // on one of them per chunk (fp32 MFMAs and these vector instructions share a SIMD's pipe: with one
+        // issuing wave per chunk that SIMD's consumer fell ~860 cycles behind and the other three waited at
+        // the barrier).  Row indices: wave 0 copies the chunk's slot_src / slot_dstl vectors into an LDS index
+        // ring by LDS-DMA 2*D chunks ahead; all waves read them from LDS D chunks ahead.  A wave issues the
+        // same number of vector-memory operations every iteration (beyond the end it re-issues the last
+        // chunk into a free slot), so "chunk it+1 has landed" is the counted wait vmcnt((D-1) * OPS).
         const int pw = wave;
-        int knext = pw;
-        int idx_h = 0, idx_g = 0;
+        constexpr int IR = 2 * D + 1;                           // index ring slots (a chunk's indices live 2D steps)
+        int* idxh = (int*)(wring + NBUF * kChunk);              // [IR][64] slot_src
+        int* idxg = idxh + IR * kChunk;                         // [IR][64] slot_dstl
         RowGather<KP, kLinear, BUF> gather_h;
         RowGather<NP, kLinear, BUF> gather_g;
         gather_h.init(lane, a.din4);
         gather_g.init(lane, a.dout4);
-        auto load_idx = [&](int k) {
-            const int kk = k < nch ? k : nch - 1;
-            const int chunk = ldc(a.rel_order, i0 + kk);
-            idx_h = a.slot_src[(size_t)chunk * kChunk + lane];
-            idx_g = a.slot_dstl[(size_t)chunk * kChunk + lane];
+        constexpr int OPS_ROWS = KP / 16 + NP / 16;             // row DMAs of one wave per chunk
+        auto chunk_of = [&](int k) { return ldc(a.rel_order, i0 + (k < nch ? k : nch - 1)); };
+        auto issue_idx = [&](int k) {                           // wave 0 only: 2 ops
+            const int chunk = chunk_of(k);
+            dma4(a.slot_src + (size_t)chunk * kChunk + lane, idxh + (k % IR) * kChunk);
+            dma4(a.slot_dstl + (size_t)chunk * kChunk + lane, idxg + (k % IR) * kChunk);
         };
-        load_idx(knext);
-        auto issue = [&](int k) {
-            const int chunk = ldc(a.rel_order, i0 + k), buf = k % NBUF;
-            const int gi = idx_h < a.n_rows ? ldc(a.chunk_tile, chunk) * a.tile + idx_g : a.n_owned;
-            gather_h.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idx_h, ringh + buf * kChunk * KP);
-            gather_g.issue(a.g, a.g_bytes, a.n_owned, a.ldg, gi, ringg + buf * kChunk * NP);
-            dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
-            knext += kProducerWaves;
-            load_idx(knext);
-        };
+        auto issue_rows = [&](int k) {                          // OPS_ROWS ops (+1 on wave 0)
+            const int chunk = chunk_of(k), buf = k % NBUF;
+            const int* ih = idxh + (k % IR) * kChunk;
+            const int* ig = idxg + (k % IR) * kChunk;
+            gather_h.issue_quarter(a.x, a.x_bytes, a.n_rows, a.ldx, ih, ringh + buf * kChunk * KP, pw);
+            // G row = first row of the chunk's tile + row in tile; padding slots (src == n_rows) -> one past the end
+            {
+                constexpr int RPI = RowGather<NP, kLinear, BUF>::RPI, QOPS = RowGather<NP, kLinear, BUF>::NOPS / 4;
+                const int base_row = ldc(a.chunk_tile, chunk) * a.tile;
+                int* gi = (int*)(wring) + 0;  // (unused; indices are combined in registers below)
+                (void)gi;
+                int grow[QOPS];
 #pragma unroll
-        for (int k = 0; k < D; ++k)
-            if (k % kProducerWaves == pw && k < nch) issue(k);
-        if (pw == 0) wait_vmcnt<0>();
+                for (int i = 0; i < QOPS; ++i) {
+                    const int r = 16 * pw + i * RPI + gather_g.rsub;
+                    grow[i] = ih[r] < a.n_rows ? base_row + ig[r] : a.n_owned;
+                }
+                const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.g, a.g_bytes);
+                const unsigned row_bytes = (unsigned)a.ldg * 4u;
+#pragma unroll
+                for (int i = 0; i < QOPS; ++i) {
+                    float* dst = ringg + buf * kChunk * NP + (16 * pw + i * RPI) * NP;
+                    const unsigned co = gather_g.coff[0];
+                    if constexpr (BUF) {
+                        const unsigned off = co == 0xFFFFFFF0u ? co : __umul24((unsigned)grow[i], row_bytes) + co;
+                        dma16_buf(rsrc, off, dst);
+                    } else {
+                        const float* gp = (grow[i] < a.n_owned && co != 0xFFFFFFF0u)
+                                              ? (const float*)((const char*)(a.g + (size_t)grow[i] * a.ldg) + co) : g_zero16;
+                        dma16(gp, dst);
+                    }
+                }
+            }
+            if (pw == 0) dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
+        };
+        auto wait_ahead = [&]() {       // everything but the (D-1) youngest iterations' operations has landed
+            if (pw == 0) wait_vmcnt<(D - 1) * (OPS_ROWS + 3)>();
+            else wait_vmcnt<(D - 1) * OPS_ROWS>();
+        };
+        // step s = { wave 0: index vectors of chunk s + 2D ; every wave: its quarter of chunk s } -- the same
+        // operation count for every s, which is what makes wait_ahead() exact from the first iteration on
+        auto step = [&](int sidx) {
+            if (pw == 0) issue_idx(sidx + 2 * D);
+            issue_rows(sidx);
+        };
+        // prologue: index vectors of chunks 0 .. 2D-1 up front, then steps 0 .. D-1
+        if (pw == 0) {
+#pragma unroll
+            for (int k = 0; k < 2 * D; ++k) issue_idx(k);
+            wait_vmcnt<0>();
+        }
+        wg_barrier();
+#pragma unroll
+        for (int k = 0; k < D; ++k) step(k);
+        wait_ahead();                                           // chunk 0 landed
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
 #endif
         for (int it = 0; it < nch; ++it) {
-            const int ki = it + D, kw = it + 1;
             STAMP(p0);
-            if (ki % kProducerWaves == pw && ki < nch) issue(ki);
+            step(it + D);
             STAMP(p1);
-            if (kw % kProducerWaves == pw && kw < nch) wait_vmcnt<0>();
+            wait_ahead();                                       // chunk it+1 landed
             STAMP(p2);
             wg_barrier();
             STAMP(p3);
@@ -1150,7 +1227,8 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
 template <int KP, int NP>
 static int launch_dw(const DwArgs& a, int nblocks, hipStream_t stream) {
     constexpr int NBUF = dw_nbuf<KP, NP>();
-    const size_t lds = sizeof(float) * ((size_t)NBUF * kChunk * (KP + NP + 1));
+    constexpr bool kWide = KP % 64 == 0 && NP % 64 == 0 && KP * NP <= 64 * 128;
+    const size_t lds = sizeof(float) * ((size_t)NBUF * kChunk * (KP + NP + 1) + (kWide ? 2 * (2 * NBUF - 1) * kChunk : 0));
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
     void (*kern)(const DwArgs);
     if constexpr (KP % 64 == 0 && NP % 64 == 0 && KP * NP <= 64 * 128)

@@ -17,7 +17,9 @@ import bench
 n, e = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda:0")
 ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, 32, 64, 64, dev)
-plans = P.build_graph_plans(ei, et, n, 32, 256)
+tile = int(os.environ.get("RGCN_TILE", P.choose_tile(n, e, 32, 64, 64)))
+plans = P.build_graph_plans(ei, et, n, 32, tile)
+print("tile", tile)
 fp = plans.fwd
 stamps = torch.zeros(fp.n_tiles * 8, dtype=torch.int64, device=dev)
 lib.rgcn_debug_set_stamps.argtypes = [ctypes.c_void_p]
