@@ -42,6 +42,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 #ifndef RGCN_SGB
 #define RGCN_SGB 0
 #endif
+#ifndef RGCN_PRIO
+#define RGCN_PRIO 3
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // weight pack
@@ -484,6 +487,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     if (wave < kProducerWaves) {
+        // The producers' few instructions must not queue behind the consumer wave's MFMAs on the shared SIMD
+        // (issue is arbitrated by priority, then age; an fp32 MFMA holds the pipe 32 cycles): RGCN_PRIO
+        __builtin_amdgcn_s_setprio(RGCN_PRIO);
         // ---- producers: LDS-DMA gather, D chunks ahead of the consumers; wave (k % 4) owns chunk k ----
         const int pw = wave;
         int knext = pw;                                   // this wave's next chunk
@@ -554,7 +560,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
 // ------------------------------------------------------------------------------------------------
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int kDwSlabsPer = 4;  // partial slabs per (workgroup, relation): one per consumer wave in the wide kernel
+constexpr int kDwSlabsPer = 8;  // partial slabs per (workgroup, relation): one per consumer wave in the wide kernel
+constexpr int kWideConsumers = 4;  // wide dW kernel: two consumer waves per SIMD (64x64), so one fills the other's stalls
 
 struct DwArgs {
     const int* rel_order;
@@ -613,7 +620,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         }
     };
     auto flush = [&]() {
-        float* slab = a.slabs + (size_t)(b + rel_cur) * kDwSlabsPer * (KP * NP);   // sub-slab 0 of 4
+        float* slab = a.slabs + (size_t)(b + rel_cur) * kDwSlabsPer * (KP * NP);   // sub-slab 0
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
             const int nt = ntb + 4 * s;
@@ -743,6 +750,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
     if (wave < kProducerWaves) {
+        // The producers' few instructions must not queue behind the consumer wave's MFMAs on the shared SIMD
+        // (issue is arbitrated by priority, then age; an fp32 MFMA holds the pipe 32 cycles): RGCN_PRIO
+        __builtin_amdgcn_s_setprio(RGCN_PRIO);
         // producers: wave (k % 4) owns chunk k of this workgroup's range (see rgcn_tile_kernel)
         const int pw = wave;
         int knext = pw;
@@ -812,9 +822,10 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
 //   of the MFMA whose 16 x 16 output tile is { dW[64u + 4 m' + j][64u' + 4 n' + j'] } -- a strided set of rows
 //   and columns, which an outer-product accumulation does not care about.
 // 3 LDS reads per 16 (KP = NP = 64) MFMAs.  The four waves' partial sums go to four sub-slabs.
-template <int KP, int NP, int NBUF, bool BUF>
-__global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs a) {
+template <int KP, int NP, int NBUF, bool BUF, int CONS>
+__global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves + CONS) / 4) rgcn_dw_wide_kernel(const DwArgs a) {
     constexpr int UA = KP / 64, UB = NP / 64;
+    constexpr int TEAMS = CONS / 4;   // consumer teams of 4 waves; team t takes the row groups g with (g + it) % TEAMS == t
     constexpr int NA = 4 * UA, NB = 4 * UB;
     constexpr int D = NBUF - 1;
     static_assert(D >= 1, "ring of at least two slots");
@@ -834,7 +845,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
     if (nch <= 0) return;
 
     if (wave >= kProducerWaves) {
-        const int cw = wave - kProducerWaves;
+        const int cwv = wave - kProducerWaves;   // slab index of this wave
+        const int cw = cwv & 3;                  // rows 4*cw + kq of a 16-row group
+        const int team = cwv >> 2;
         const int ml = lane & 15, kq = lane >> 4;
         f32x4 acc[NA][NB];
         float bsum[NB];
@@ -848,7 +861,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
             }
         };
         auto flush = [&]() {
-            float* slab = a.slabs + ((size_t)(b + rel_cur) * kDwSlabsPer + cw) * (KP * NP);
+            float* slab = a.slabs + ((size_t)(b + rel_cur) * kDwSlabsPer + cwv) * (KP * NP);
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia)
 #pragma unroll
@@ -866,7 +879,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
                     v += __shfl_xor(v, 16);
                     v += __shfl_xor(v, 32);
                     if (kq == 0)
-                        a.bias_slabs[((size_t)b * kDwSlabsPer + cw) * NP + 64 * (jb >> 2) + 4 * ml + (jb & 3)] = v;
+                        a.bias_slabs[((size_t)b * kDwSlabsPer + cwv) * NP + 64 * (jb >> 2) + 4 * ml + (jb & 3)] = v;
                 }
             }
         };
@@ -929,14 +942,18 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
                         acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a4[ia >> 2][ia & 3], bv[jb], acc[ia][jb], 0, 0, 0);
             };
             const int ngrp = (cnt + 15) >> 4;
+            // this team's groups: g0, g0 + TEAMS, ...; the starting team alternates with the chunk so that
+            // chunks with an odd number of groups load both teams evenly
+            const int g0 = (team + it) % TEAMS;
             Grp grp[2];
-            load_grp(grp[0], 0);
+            if (g0 < ngrp) load_grp(grp[0], g0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int gi = 0; gi < kChunk / 16; ++gi) {
-                if (gi < ngrp) {
-                    if (gi + 1 < ngrp) {
-                        load_grp(grp[(gi + 1) & 1], gi + 1);
+            for (int gi = 0; gi < kChunk / 16 / TEAMS; ++gi) {
+                const int g = g0 + gi * TEAMS;
+                if (g < ngrp) {
+                    if (g + TEAMS < ngrp) {
+                        load_grp(grp[(gi + 1) & 1], g + TEAMS);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     compute_grp(grp[gi & 1]);
@@ -950,7 +967,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
             STAMP_ADD(st_bar, t2, t3);
         }
 #ifdef RGCN_STAMPS
-        if (g_stamps && cw == 0 && lane == 0) {
+        if (g_stamps && cwv == 0 && lane == 0) {
             unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
             o[0] = st_scal; o[1] = st_comp; o[2] = 0; o[3] = st_bar;
         }
@@ -959,6 +976,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_wide_kernel(const DwArgs 
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
     if (wave < kProducerWaves) {
+        // The producers' few instructions must not queue behind the consumer wave's MFMAs on the shared SIMD
+        // (issue is arbitrated by priority, then age; an fp32 MFMA holds the pipe 32 cycles): RGCN_PRIO
+        __builtin_amdgcn_s_setprio(RGCN_PRIO);
         // producers, wide kernel: EVERY producer wave issues a quarter of every chunk (rows 16*pw..+15 of the H
         // and of the G slot), so the DMA-issue instructions are spread over the four SIMDs instead of landing
         // on one of them per chunk (fp32 MFMAs and these vector instructions share a SIMD's pipe: with one
@@ -1231,13 +1251,19 @@ static int launch_dw(const DwArgs& a, int nblocks, hipStream_t stream) {
     const size_t lds = sizeof(float) * ((size_t)NBUF * kChunk * (KP + NP + 1) + (kWide ? 2 * (2 * NBUF - 1) * kChunk : 0));
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
     void (*kern)(const DwArgs);
-    if constexpr (KP % 64 == 0 && NP % 64 == 0 && KP * NP <= 64 * 128)
-        kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_wide_kernel<KP, NP, NBUF, true> : rgcn_dw_wide_kernel<KP, NP, NBUF, false>;
-    else
+    int threads = kThreads;
+    if constexpr (kWide) {
+        // 64x64: accumulators take 64 registers, two consumer teams fit; wider: one team
+        constexpr int CONS = KP * NP <= 64 * 64 ? kWideConsumers : 4;
+        threads = 64 * (kProducerWaves + CONS);
+        kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_wide_kernel<KP, NP, NBUF, true, CONS>
+                                        : rgcn_dw_wide_kernel<KP, NP, NBUF, false, CONS>;
+    } else {
         kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_kernel<KP, NP, NBUF, true> : rgcn_dw_kernel<KP, NP, NBUF, false>;
+    }
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, a);
     return (int)hipGetLastError();
 }
 
