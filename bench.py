@@ -113,11 +113,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RGCN_BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the N > 1 code path on a 1-GPU box
+    backend = os.environ.get("RGCN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import __graft_entry__ as ge
@@ -142,8 +148,10 @@ def main():
     plans = conv._plans(x, ei, et)          # one-time graph plan (excluded from the metric)
     torch.cuda.synchronize()
     plan_s = time.perf_counter() - t0
-    log(f"plan built in {plan_s:.2f}s: fwd {plans.fwd.n_chunks} chunks / {plans.fwd.n_tiles} tiles, "
-        f"bwd {plans.bwd.n_chunks} chunks, {(plans.fwd.nbytes() + plans.bwd.nbytes()) / 1e9:.2f} GB")
+    _pl = [plans] if world == 1 else plans.pieces
+    log(f"plan built in {plan_s:.2f}s: fwd {sum(p.fwd.n_chunks for p in _pl)} chunks / "
+        f"{sum(p.fwd.n_tiles for p in _pl)} tiles, bwd {sum(p.bwd.n_chunks for p in _pl)} chunks, "
+        f"{sum(p.fwd.nbytes() + p.bwd.nbytes() for p in _pl) / 1e9:.2f} GB, tile {_pl[0].fwd.tile}")
 
     def step():
         x.grad = None
@@ -173,20 +181,33 @@ def main():
     log(f"{args.steps} timed steps: {dt / args.steps * 1e3:.2f} ms/step")
 
     # ---- per-launch timing of the three hot kernels (HIP events on the launch stream) --------------
-    fp, bp = plans.fwd, plans.bwd
+    fps = [plans.fwd] if world == 1 else [p.fwd for p in plans.pieces]
+    bps = [plans.bwd] if world == 1 else [p.bwd for p in plans.pieces]
+    fps = [p for p in fps if p.n_owned > 0]
+    bps = [p for p in bps if p.n_owned > 0]
     xd = x.detach()
     wf, rt, bs = conv.weight.detach(), conv.root.detach(), conv.bias.detach()
-    out = torch.empty(max(fp.n_owned, 1), d, device=dev)
-    dxb = torch.empty(max(bp.n_owned, 1), d, device=dev)
+    rows_max = max([p.n_owned for p in fps + bps] + [1])
+    out = torch.empty(rows_max, d, device=dev)
+    dxb = torch.empty(rows_max, d, device=dev)
     dw, dr, db = torch.empty_like(wf), torch.empty_like(rt), torch.empty_like(bs)
     pk, pkt = _lib.pack_weights(wf, rt, False), _lib.pack_weights(wf, rt, True)
-    psf, psb = _lib.plan_struct(fp), _lib.plan_struct(bp)
-    g_own = dg[fp.node_begin:fp.node_end]
-    launches = {
-        "fwd": lambda: _lib.fwd(psf, xd, d, pk, bs, out, d),
-        "dx": lambda: _lib.bwd_dx(psb, dg, d, pkt, dxb, d),
-        "dw": lambda: _lib.bwd_dw(psf, xd, d, g_own, d, dw, dr, db),
-    }
+    psf = [(_lib.plan_struct(p), p) for p in fps]
+    psb = [(_lib.plan_struct(p), p) for p in bps]
+
+    def run_fwd():
+        for ps, p in psf:
+            _lib.fwd(ps, xd, d, pk, bs, out[:p.n_owned], d)
+
+    def run_dx():
+        for ps, p in psb:
+            _lib.bwd_dx(ps, dg, d, pkt, dxb[:p.n_owned], d)
+
+    def run_dw():
+        for ps, p in psf:
+            _lib.bwd_dw(ps, xd, d, dg[p.node_begin:p.node_end], d, dw, dr, db)
+
+    launches = {"fwd": run_fwd, "dx": run_dx, "dw": run_dw}
     kernel_ms = {}
     reps = max(3, min(args.steps, 10))
     for name, fn in launches.items():
@@ -242,7 +263,7 @@ def main():
                          "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms},
             "kernel_ms": kernel_ms,
             "plan_build_s": plan_s,
-            "plan_bytes": fp.nbytes() + bp.nbytes(),
+            "plan_bytes": sum(p.nbytes() for p in fps + bps),
         }
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline sample")

@@ -48,15 +48,45 @@ def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int
 
 
 class DistContext:
-    """One process per GPU; output nodes cut into equal tile-aligned ranges (see dist.py)."""
+    """One process per GPU.  Output nodes are cut into ``pieces * world`` equal tile-aligned blocks, dealt
+    piece-major: block (s, r) = rows [(s * world + r) * piece_rows, +piece_rows) belongs to rank r.  A rank
+    computes piece s straight into its block of the gathered buffer and all-gathers the contiguous
+    super-block s asynchronously while it computes piece s + 1 (dist.py)."""
 
-    def __init__(self, group, rank: int, world: int, rows_per_rank: int):
-        self.group, self.rank, self.world, self.rows_per_rank = group, rank, world, rows_per_rank
+    def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int):
+        self.group, self.rank, self.world = group, rank, world
+        self.piece_rows, self.pieces = piece_rows, pieces
 
-    def node_range(self, n_nodes: int) -> Tuple[int, int]:
-        b = min(self.rank * self.rows_per_rank, n_nodes)
-        e = min(b + self.rows_per_rank, n_nodes)
-        return b, e
+    @property
+    def total_rows(self) -> int:
+        return self.pieces * self.world * self.piece_rows
+
+    def block(self, s: int, r: Optional[int] = None) -> Tuple[int, int]:
+        r = self.rank if r is None else r
+        b = (s * self.world + r) * self.piece_rows
+        return b, b + self.piece_rows
+
+    def node_range(self, s: int, n_nodes: int, r: Optional[int] = None) -> Tuple[int, int]:
+        b, e = self.block(s, r)
+        return min(b, n_nodes), min(e, n_nodes)
+
+
+def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, device) -> Tensor:
+    """Run ``launch(plan, out_rows)`` for every piece this rank owns and all-gather the pieces, overlapping
+    the collective of piece s (RCCL's own stream) with the kernels of piece s + 1 (current stream)."""
+    full = torch.empty(dctx.total_rows, ld, dtype=torch.float32, device=device)
+    handles = []
+    w, pr = dctx.world, dctx.piece_rows
+    for s_idx, plan in enumerate(plans_list):
+        b, _ = dctx.block(s_idx)
+        mine = full[b:b + pr]
+        if plan.n_owned > 0:
+            launch(plan, mine)
+        sup = full[s_idx * w * pr:(s_idx + 1) * w * pr]
+        handles.append(torch.distributed.all_gather_into_tensor(sup, mine, group=dctx.group, async_op=True))
+    for h in handles:
+        h.wait()
+    return full[:n]
 
 
 class _RGCNLayerFn(torch.autograd.Function):
@@ -68,7 +98,7 @@ class _RGCNLayerFn(torch.autograd.Function):
                 plans: GraphPlans, dctx: Optional[DistContext]):
         n, din = x.shape
         num_rel, _, dout = w_full.shape
-        fp: TilePlan = plans.fwd
+        fp: Optional[TilePlan] = plans.fwd if dctx is None else None
         xp = _rows16(x, din)
         wf = w_full.detach().float().contiguous()
         rt = None if root is None else root.detach().float().contiguous()
@@ -79,16 +109,12 @@ class _RGCNLayerFn(torch.autograd.Function):
             out = torch.empty(n, ldo, dtype=torch.float32, device=x.device)
             _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, out, dout)
         else:
-            # every rank computes its own node range straight into its slice of the gathered buffer;
-            # with destination-range ownership the per-layer all-reduce of SURVEY.md 8e degenerates to
-            # this all-gather (each row has exactly one non-zero contributor)
-            rows = dctx.rows_per_rank
-            full = torch.empty(dctx.world * rows, ldo, dtype=torch.float32, device=x.device)
-            mine = full[dctx.rank * rows:(dctx.rank + 1) * rows]
-            if fp.n_owned > 0:
-                _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, mine, dout)
-            torch.distributed.all_gather_into_tensor(full, mine, group=dctx.group)
-            out = full[:n]
+            # every rank computes its own blocks straight into the gathered buffer; with destination-range
+            # ownership the per-layer all-reduce of SURVEY.md 8e degenerates to an all-gather (each row has
+            # exactly one non-zero contributor), issued piece by piece under the next piece's kernels
+            out = _gather_pieces(dctx, [p.fwd for p in plans.pieces],
+                                 lambda pl, rows: _lib.fwd(_lib.plan_struct(pl), xp, din, packed, bs, rows, dout),
+                                 ldo, n, x.device)
         ctx.plans, ctx.dctx = plans, dctx
         ctx.dims = (n, din, dout, num_rel)
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
@@ -104,32 +130,40 @@ class _RGCNLayerFn(torch.autograd.Function):
         gp = _rows16(g, dout)
         dx = dw = droot = dbias = None
         if need_x:
-            bp: TilePlan = plans.bwd
             packed_t = _lib.pack_weights(wf, rt, transpose=True)
             ldx = _round4(din)
             if dctx is None:
                 dxp = torch.empty(n, ldx, dtype=torch.float32, device=g.device)
-                _lib.bwd_dx(_lib.plan_struct(bp), gp, dout, packed_t, dxp, din)
+                _lib.bwd_dx(_lib.plan_struct(plans.bwd), gp, dout, packed_t, dxp, din)
             else:
-                rows = dctx.rows_per_rank
-                full = torch.empty(dctx.world * rows, ldx, dtype=torch.float32, device=g.device)
-                mine = full[dctx.rank * rows:(dctx.rank + 1) * rows]
-                if bp.n_owned > 0:
-                    _lib.bwd_dx(_lib.plan_struct(bp), gp, dout, packed_t, mine, din)
-                torch.distributed.all_gather_into_tensor(full, mine, group=dctx.group)
-                dxp = full[:n]
+                dxp = _gather_pieces(dctx, [p.bwd for p in plans.pieces],
+                                     lambda pl, rows: _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din),
+                                     ldx, n, g.device)
             dx = dxp if ldx == din else dxp[:, :din]
         need_root = need_root and ctx.has_root
         need_bias = need_bias and ctx.has_bias
         if need_w or need_root or need_bias:
-            fp: TilePlan = plans.fwd
             dev = g.device
-            dw = torch.zeros(num_rel, din, dout, dtype=torch.float32, device=dev) if need_w else None
-            droot = torch.zeros(din, dout, dtype=torch.float32, device=dev) if need_root else None
-            dbias = torch.zeros(dout, dtype=torch.float32, device=dev) if need_bias else None
-            if fp.n_owned > 0:
-                g_own = gp[fp.node_begin:fp.node_end]
-                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, g_own, dout, dw, droot, dbias)
+            fplans = [plans.fwd] if dctx is None else [p.fwd for p in plans.pieces]
+            acc = None
+            for fp in fplans:
+                if fp.n_owned <= 0:
+                    continue
+                pw = torch.empty(num_rel, din, dout, dtype=torch.float32, device=dev) if need_w else None
+                pr = torch.empty(din, dout, dtype=torch.float32, device=dev) if need_root else None
+                pb = torch.empty(dout, dtype=torch.float32, device=dev) if need_bias else None
+                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb)
+                if acc is None:
+                    acc = [pw, pr, pb]
+                else:
+                    for t, u in zip(acc, (pw, pr, pb)):
+                        if t is not None:
+                            t.add_(u)
+            if acc is None:
+                acc = [torch.zeros(num_rel, din, dout, device=dev) if need_w else None,
+                       torch.zeros(din, dout, device=dev) if need_root else None,
+                       torch.zeros(dout, device=dev) if need_bias else None]
+            dw, droot, dbias = acc
             if dctx is not None:
                 for t in (dw, droot, dbias):
                     if t is not None:

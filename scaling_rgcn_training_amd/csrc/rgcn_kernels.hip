@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
 // ------------------------------------------------------------------------------------------------
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int kDwSlabsPer = 8;  // partial slabs per (workgroup, relation): one per consumer wave in the wide kernel
+constexpr int kDwSlabsPer = 4;  // partial slabs per (workgroup, relation): one per consumer wave in the wide kernel
 constexpr int kWideConsumers = 4;  // wide dW kernel: two consumer waves per SIMD (64x64), so one fills the other's stalls
 
 struct DwArgs {
@@ -829,6 +829,7 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
     constexpr int NA = 4 * UA, NB = 4 * UB;
     constexpr int D = NBUF - 1;
     static_assert(D >= 1, "ring of at least two slots");
+    static_assert(CONS <= kDwSlabsPer, "one partial slab per consumer wave");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ringh = lds;                                   // [NBUF][64][KP]

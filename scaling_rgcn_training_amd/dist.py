@@ -1,15 +1,16 @@
 """One process per GPU over RCCL (``torch.distributed`` backend ``nccl``) / gloo on CPU for tests.
 
-Edge partition: output nodes are cut into ``world`` equal, tile-aligned ranges.
-Rank p owns the forward plan of the edges INTO its range (so every (dst, relation) mean is local)
-and the transposed plan of the edges OUT OF its range (so every dX row is complete locally).
-Features are replicated (2.56 GB at the 10M-node config, against 288 GB of HBM).  Per layer:
+Edge partition: output nodes are cut into ``pieces * world`` equal, tile-aligned blocks
+dealt piece-major (conv.DistContext).  Rank p owns the forward plans of the edges INTO its blocks (so every
+(dst, relation) mean is local) and the transposed plans of the edges OUT OF its blocks (so every dX row is
+complete locally).  Features are replicated (2.56 GB at the 10M-node config, against 288 GB of HBM).  Per layer:
 
-* forward : each rank writes its rows into its slice of the gathered buffer, then ONE all-gather
-            (the all-reduce of per-node aggregated features with exactly one contributor per row);
-* backward: dX rows likewise (all-gather), weight gradients all-reduced (~0.5 MB).
+* forward : each rank writes a block into its place in the gathered buffer and all-gathers the super-block
+            asynchronously while the next block's kernels run (the all-reduce of per-node aggregated features
+            with exactly one contributor per row, pipelined in ``PIECES`` stages);
+* backward: dX blocks likewise, weight gradients all-reduced (~0.5 MB).
 
-Because range boundaries are tile multiples, a rank's tiles and chunks are exactly the single-GPU
+Because block boundaries are tile multiples, a rank's tiles and chunks are exactly the single-GPU
 ones, so P-rank outputs and dX are bit-identical to 1-rank ones; only d_weight sums differ in order.
 """
 from __future__ import annotations
@@ -24,34 +25,48 @@ from .conv import DistContext, RGCNConv
 from .plan import GraphPlans, build_graph_plans, cached_graph_plans
 
 
-def rows_per_rank(n_nodes: int, tile: int, world: int) -> int:
+PIECES = 4  # all-gather pipeline depth: the collective of piece s runs under the kernels of piece s + 1
+
+
+def piece_rows(n_nodes: int, tile: int, world: int, pieces: int) -> int:
     n_tiles = (n_nodes + tile - 1) // tile
-    return ((n_tiles + world - 1) // world) * tile
+    return ((n_tiles + world * pieces - 1) // (world * pieces)) * tile
 
 
-def make_context(n_nodes: int, tile: int, group=None) -> Optional[DistContext]:
+def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES) -> Optional[DistContext]:
     if not dist.is_available() or not dist.is_initialized():
         return None
     world = dist.get_world_size(group)
     if world == 1:
         return None
-    return DistContext(group, dist.get_rank(group), world, rows_per_rank(n_nodes, tile, world))
+    n_tiles = (n_nodes + tile - 1) // tile
+    pieces = max(1, min(pieces, n_tiles // world if n_tiles >= world else 1))
+    return DistContext(group, dist.get_rank(group), world, piece_rows(n_nodes, tile, world, pieces), pieces)
+
+
+class RankPlans:
+    """The graph plans of one rank: one forward / transposed pair per owned block (piece)."""
+
+    def __init__(self, pieces):
+        self.pieces = pieces
+        self.num_edges = sum(p.num_edges for p in pieces)
 
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
-               aggr: str, rank: int, world: int) -> GraphPlans:
-    rows = rows_per_rank(n_nodes, tile, world)
-    b = min(rank * rows, n_nodes)
-    e = min(b + rows, n_nodes)
-    return build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr,
-                             fwd_range=(b, e), bwd_range=(b, e))
+               aggr: str, dctx: DistContext) -> RankPlans:
+    out = []
+    for s in range(dctx.pieces):
+        b, e = dctx.node_range(s, n_nodes)
+        out.append(build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr,
+                                     fwd_range=(b, e), bwd_range=(b, e)))
+    return RankPlans(out)
 
 
-def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext) -> GraphPlans:
+def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext) -> RankPlans:
     return cached_graph_plans(
         edge_index, edge_type, n_nodes, num_relations, tile, aggr,
-        builder=lambda: rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx.rank, dctx.world),
-        extra_key=("rank", dctx.rank, dctx.world))
+        builder=lambda: rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx),
+        extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, dctx.piece_rows))
 
 
 def attach(module: torch.nn.Module, n_nodes: int, n_edges: int, group=None) -> None:

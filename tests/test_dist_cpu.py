@@ -36,30 +36,34 @@ def _worker(rank, world, port, ret):
     x = torch.randn(n, din, generator=g).double()
     dg = torch.randn(n, dout, generator=g).double()
     w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0).astype(np.float64)
-    ctx = rdist.make_context(n, tile)
-    assert ctx is not None and ctx.world == world and ctx.rank == rank
-    plans = rdist.rank_plans(ei, et, n, r, tile, "mean", rank, world)
-    rows = ctx.rows_per_rank
-    # forward: own rows into the own slice of the gathered buffer, then ONE all-gather (conv.py forward)
-    full = torch.zeros(world * rows, dout, dtype=torch.float64)
-    mine = full[rank * rows:(rank + 1) * rows]
-    if plans.fwd.n_owned:
-        mine[:plans.fwd.n_owned] = torch.from_numpy(emulate_spmm(plans.fwd, x.numpy(), w_all, bias.numpy()))
-    dist.all_gather_into_tensor(full, mine.clone())
-    out = full[:n]
-    # backward dX on the transposed plan, same gather
-    fullx = torch.zeros(world * rows, din, dtype=torch.float64)
-    minex = fullx[rank * rows:(rank + 1) * rows]
-    if plans.bwd.n_owned:
-        minex[:plans.bwd.n_owned] = torch.from_numpy(
-            emulate_spmm(plans.bwd, dg.numpy(), np.transpose(w_all, (0, 2, 1))))
-    dist.all_gather_into_tensor(fullx, minex.clone())
-    dx = fullx[:n]
-    # weight gradients: partial over the own rows, all-reduced
+    ctx = rdist.make_context(n, tile, pieces=3)
+    assert ctx is not None and ctx.world == world and ctx.rank == rank and ctx.pieces == 3
+    plans = rdist.rank_plans(ei, et, n, r, tile, "mean", ctx)
+    pr, tot = ctx.piece_rows, ctx.total_rows
+
+    def gather(plan_list, feat, w_mats, b_vec, width):
+        """conv._gather_pieces with the numpy plan walk as the kernel: own block -> async all-gather of its super-block"""
+        full = torch.zeros(tot, width, dtype=torch.float64)
+        handles = []
+        for s_idx, pl in enumerate(plan_list):
+            b, _ = ctx.block(s_idx)
+            mine = full[b:b + pr]
+            if pl.n_owned:
+                mine[:pl.n_owned] = torch.from_numpy(emulate_spmm(pl, feat, w_mats, b_vec))
+            sup = full[s_idx * world * pr:(s_idx + 1) * world * pr]
+            handles.append(dist.all_gather_into_tensor(sup, mine.clone(), async_op=True))
+        for h in handles:
+            h.wait()
+        return full[:n]
+
+    out = gather([p.fwd for p in plans.pieces], x.numpy(), w_all, bias.numpy(), dout)
+    dx = gather([p.bwd for p in plans.pieces], dg.numpy(), np.transpose(w_all, (0, 2, 1)), None, din)
+    # weight gradients: partial over the own blocks, all-reduced
     dw = torch.zeros(r + 1, din, dout, dtype=torch.float64)
-    if plans.fwd.n_owned:
-        b, e_ = plans.fwd.node_begin, plans.fwd.node_end
-        dw = torch.from_numpy(emulate_dw(plans.fwd, x.numpy(), dg.numpy()[b:e_], r + 1, din, dout))
+    for p in plans.pieces:
+        if p.fwd.n_owned:
+            b, e_ = p.fwd.node_begin, p.fwd.node_end
+            dw += torch.from_numpy(emulate_dw(p.fwd, x.numpy(), dg.numpy()[b:e_], r + 1, din, dout))
     dist.all_reduce(dw)
     if rank == 0:
         ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(),

@@ -74,17 +74,20 @@ def test_metrics_match_definitions():
     assert lf is T.bce_loss
 
 
-def test_rank_ranges_tile_aligned_and_cover():
-    for n, tile, world in ((1000, 256, 2), (10_000_000, 256, 8), (300, 128, 4), (5, 256, 2)):
-        rows = rdist.rows_per_rank(n, tile, world)
-        assert rows % tile == 0 and rows * world >= n
-        covered = 0
+def test_rank_blocks_tile_aligned_and_cover():
+    from scaling_rgcn_training_amd.conv import DistContext
+    for n, tile, world, pieces in ((1000, 256, 2, 1), (10_000_000, 384, 8, 4), (300, 128, 4, 1), (5, 256, 2, 1),
+                                   (100_000, 64, 2, 4)):
+        pr = rdist.piece_rows(n, tile, world, pieces)
+        assert pr % tile == 0 and pr * world * pieces >= n
+        seen = np.zeros(n, dtype=np.int32)
         for r in range(world):
-            b = min(r * rows, n)
-            e = min(b + rows, n)
-            assert b % tile == 0 or b == n
-            covered += e - b
-        assert covered == n
+            c = DistContext(None, r, world, pr, pieces)
+            for s_ in range(pieces):
+                b, e = c.node_range(s_, n)
+                assert b % tile == 0 or b == n
+                seen[b:e] += 1
+        assert np.all(seen == 1)                     # every node owned by exactly one (rank, piece)
 
 
 def test_choose_tile_respects_lds_and_prefers_full_chunks():
