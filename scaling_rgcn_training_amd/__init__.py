@@ -8,7 +8,8 @@ Sub-modules:
 * ``conv``    -- ``RGCNConv``: PyG-2.3.1-compatible ``nn.Module`` whose forward/backward are the HIP kernels
 * ``data``    -- ``Data`` attribute bag (stand-in for ``torch_geometric.data.Data``)
 * ``layers``  -- ``Emb_Layers`` / ``Emb_ATT_Layers`` / ``Emb_MLP_Layers`` (reference model/layers.py API)
-* ``trainer`` -- full-batch loop of reference model/modelTrainer.py
+* ``trainer`` -- full-batch loop of reference model/modelTrainer.py (+ device-correct evaluation)
+* ``graphs``  -- N-Triples ingest, dataset assembly, summary -> original embedding transfer (graphs/*.py, embeddingTricks.py)
 * ``dist``    -- one-process-per-GPU edge partition + per-layer collective over RCCL
 
 There is no CPU compute path: the layer raises if the HIP library or a GPU is missing.
