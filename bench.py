@@ -233,9 +233,9 @@ def main():
     # gfx950 correction applied) committed under profiles/ -- only quoted for the workload they were taken on
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
         if world == 1 and (n, e, r, d) == (10_000_000, 100_000_000, 32, 64):
-            key = "rgcn::rgcn_tile_kernel<64, 64, 3, true>" if "tile" in kname else "rgcn::rgcn_dw_wide_kernel<64, 64, 4, true>"
+            key = "rgcn::rgcn_tile_kernel<64, 64, 3, true>" if "tile" in kname else "rgcn::rgcn_dw_wide_kernel<64, 64, 4, true, 4>"
             traffic = pm["kernels"][key]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
