@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 3
+#define RGCN_ABI_VERSION 4
 #define RGCN_CHUNK 64 /* edge slots per chunk == rows of one LDS ring slot */
 #define RGCN_MAX_WIDTH 128
 
@@ -69,10 +69,10 @@ typedef struct rgcn_plan {
     const int32_t* slot_src;   /* [n_chunks * 64] row to gather; padding = n_nodes (one past the last row) */
     const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */
     const int32_t* slot_dstl;  /* [n_chunks * 64] row inside the tile, ascending inside a chunk; padding = tile */
-    const int32_t* slot_acc;   /* [n_chunks * 64] forward run-sum metadata per slot: low 16 bits = accumulator row
-                                * written (slot_dstl if the slot ends a run of equal destinations inside its
-                                * 16-slot MFMA row tile, else `tile`), high 16 bits = position (0..15) in the
-                                * row tile of the slot ending this slot's run */
+    const int32_t* slot_acc;   /* [n_chunks * 64] forward run-sum metadata per slot: (accumulator row written) << 8
+                                * | (position 0..15 in the 16-slot MFMA row tile of the slot ending this slot's
+                                * run of equal destinations); the row is slot_dstl if the slot ends its run,
+                                * else `tile` (dummy row) */
 } rgcn_plan_t;
 
 int rgcn_abi_version(void);

@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         const bool active = cwv < CW;
         const int cw = cwv;
         const int rowl = lane & 15, kq = lane >> 4;
+        const unsigned lane_col_bytes = (unsigned)(16 * cw + rowl) * 4u;   // this lane's column in slice 0
         const f32x4* wp4 = (const f32x4*)a.wp;
         f32x4 bcur[SL][KT], bnext[SL][KT];
         int rel_cur = ldc(a.chunk_rel, c0);
@@ -324,10 +325,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             };
             // per-tile state carried between the pipeline stages below
             struct Tile {
-                f32x4 y[SL];      // H W_r of the tile (main MFMA result), this wave's column slices
-                f32x4 z[SL][2];   // run sums (two accumulation chains)
+                f32x4 y[SL];      // H W_r of the tile (main MFMA result); after stage B: one addend of the update
+                f32x4 z[SL];      // after stage B: the other addend (old accumulator contents [+ run sums])
                 float* dst[4];    // accumulator rows this lane updates
-                float old[SL][4]; // their previous contents
             };
             auto load_ops = [&](Ops& o, int rt) {
                 const int row = rt * 16 + rowl;
@@ -363,56 +363,60 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             // pairwise distinct destinations inside the tile.  Y's accumulator registers are already in
             // B-operand layout for MFMA step i with k = 4*k' + i: no data movement.  The accumulator reads
             // of stage C are issued here (after the previous tile's stage-C writes in program order).
+            // byte offset of accumulator row (d >> 8) in the LDS tile, plus this lane's column: one bit-field
+            // insert when a row is 256 B (NP = 64), shift + insert otherwise
+            auto acc_ptr = [&](int d) -> float* {
+                constexpr unsigned kRowMask = 0xFFFFFF00u;
+                unsigned off;
+                if constexpr (NP == 64) off = ((unsigned)d & kRowMask) | lane_col_bytes;
+                else off = (((unsigned)d >> 8) * (NP * 4)) + lane_col_bytes;
+                return (float*)((char*)out_lds + off);
+            };
             auto stage_b = [&](const Ops& o, Tile& t, bool dup) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t.dst[i] = acc_ptr(o.d4[i]);
                 if (!dup) {
                     // no destination repeats inside this row tile (the plan spreads a run over different
-                    // tiles whenever it can): every row ends its own run, P would be diag(w) -- skip the product
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) t.dst[i] = out_lds + (o.d4[i] & 0xFFFF) * NP + 16 * cw + rowl;
+                    // tiles whenever it can): every row ends its own run, P would be diag(w) -- no product,
+                    // and the accumulate is one fused multiply-add per element: acc_new = y * w + acc_old
 #pragma unroll
                     for (int s = 0; s < SL; ++s) {
+                        f32x4 old;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) t.old[s][i] = t.dst[i][16 * CW * s];
-                        t.z[s][0] = t.y[s] * o.w4;
-                        t.z[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int i = 0; i < 4; ++i) old[i] = t.dst[i][16 * CW * s];
+                        t.z[s] = old;
+                        t.y[s] = t.y[s] * o.w4;      // finished in stage C as z + y
                     }
                     return;
                 }
                 float pm[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    // row 4*kq + i belongs to the run that ends at tile row (d >> 16); this lane supplies
+                    // row 4*kq + i belongs to the run that ends at tile row (d & 0xFF); this lane supplies
                     // P[m = rowl][k = 4*kq + i]
-                    pm[i] = ((unsigned)o.d4[i] >> 16) == (unsigned)rowl ? o.w4[i] : 0.f;
-                    // run ends write their destination row, everything else the dummy row (already encoded)
-                    t.dst[i] = out_lds + (o.d4[i] & 0xFFFF) * NP + 16 * cw + rowl;
+                    pm[i] = ((unsigned)o.d4[i] & 0xFFu) == (unsigned)rowl ? o.w4[i] : 0.f;
                 }
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
+                    // the accumulator's old contents are the C operand of the first run-sum MFMA: Z = P.Y + old
+                    f32x4 old;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) t.old[s][i] = (RGCN_ABL & 4) ? 0.f : t.dst[i][16 * CW * s];
-                    f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-                    if (RGCN_ABL & 2) {
-                        t.z[s][0] = t.y[s] * pm[0];
-                        t.z[s][1] = t.y[s] * pm[1] + pm[2] + pm[3];
-                        continue;
-                    }
-                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], t.y[s][0], z0, 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) old[i] = t.dst[i][16 * CW * s];
+                    f32x4 z1 = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], t.y[s][0], old, 0, 0, 0);
                     z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], t.y[s][1], z1, 0, 0, 0);
-                    t.z[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], t.y[s][2], z0, 0, 0, 0);
-                    t.z[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], t.y[s][3], z1, 0, 0, 0);
+                    t.z[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], t.y[s][2], z0, 0, 0, 0);
+                    t.y[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], t.y[s][3], z1, 0, 0, 0);
                 }
             };
-            // stage C: plain read-modify-write of the tile accumulator (this wave owns these columns)
+            // stage C: write back acc_new = z + y (both paths leave the two addends there); this wave owns
+            // these columns and the rows written by one instruction are pairwise distinct: plain stores
             auto stage_c = [&](Tile& t) {
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
-                    const f32x4 z = t.z[s][0] + t.z[s][1];
+                    const f32x4 v = t.z[s] + t.y[s];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (RGCN_ABL & 4) asm volatile("" ::"v"(t.old[s][i] + z[i]), "v"(t.dst[i]));
-                        else t.dst[i][16 * CW * s] = t.old[s][i] + z[i];
-                    }
+                    for (int i = 0; i < 4; ++i) t.dst[i][16 * CW * s] = v[i];
                 }
             };
             // One straight-line block per tile count (1..4) so hipcc can interleave freely.  Software

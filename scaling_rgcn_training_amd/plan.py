@@ -19,7 +19,7 @@ Layout (all int32 / float32, device resident):
   ``1 / max(1, c[dst, rel])`` for ``aggr='mean'``, 0 = padding), ``slot_dstl`` (row inside the tile,
   ``tile`` = padding: the kernels keep one dummy accumulator row there); inside a chunk the slots are
   sorted by ``slot_dstl``, which the forward kernel's run-sum relies on; ``slot_acc`` packs what that
-  run-sum needs per slot (accumulator row | run-end position << 16, see ``run_metadata``);
+  run-sum needs per slot (accumulator row << 8 | run-end position, see ``run_metadata``);
   duplicate (src, dst, relation) triples share ONE slot whose weight is the sum of theirs;
 * per chunk: ``chunk_rel``, ``chunk_cnt`` (slots of the used 16-slot row tiles), ``chunk_tile``, ``chunk_flags``; ``tile_ptr`` gives the tile-major
   chunk ranges (forward / dX kernels) and ``rel_order`` the relation-major order (dW kernel).
@@ -58,7 +58,7 @@ class TilePlan:
     slot_src: Tensor      # int32 [n_chunks * CHUNK]
     slot_w: Tensor        # float32 [n_chunks * CHUNK]
     slot_dstl: Tensor     # int32 [n_chunks * CHUNK]
-    slot_acc: Tensor      # int32 [n_chunks * CHUNK]  accumulator row | run-end position << 16
+    slot_acc: Tensor      # int32 [n_chunks * CHUNK]  accumulator row << 8 | run-end position
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -231,9 +231,11 @@ def run_metadata(slot_dstl: Tensor, tile: int):
     """Per slot, for the forward kernel's run-sum (csrc/rgcn_kernels.hip stage B/C), precomputed here so
     the kernel spends no vector instructions on it: inside every 16-slot MFMA row tile, slots with equal
     destination are adjacent (tiles are sorted by destination) and form a RUN; the run's sum is written by
-    its LAST slot only.  Returns (slot_acc, tile_dup).  slot_acc low 16 bits: accumulator row the slot writes
-    (its destination if it ends a run, else the dummy row ``tile``; padding slots carry destination ``tile``
-    already); high 16 bits: position (0..15) inside the row tile of the slot that ends this slot's run.
+    its LAST slot only.  Returns (slot_acc, tile_dup).  slot_acc = (accumulator row the slot writes) << 8 |
+    (position 0..15 inside the row tile of the slot that ends this slot's run).  The accumulator row is the
+    slot's destination if it ends a run, else the dummy row ``tile`` (padding slots carry destination ``tile``
+    already); shifted by 8 it IS the byte offset of that row in a 64-float-wide LDS accumulator, so the kernel
+    forms an address with one bit-field insert.
     tile_dup[t]: row tile t contains a run longer than one slot (needs the run-sum product)."""
     g = ROWS_PER_MFMA_TILE
     d = slot_dstl.view(-1, g).to(torch.int64)
@@ -244,7 +246,7 @@ def run_metadata(slot_dstl: Tensor, tile: int):
     runend = torch.flip(torch.cummin(torch.flip(endpos, [1]), dim=1).values, [1])
     acc = torch.where(is_end, d, torch.full_like(d, tile))
     tile_dup = ((~is_end) & (d != tile)).any(dim=1)     # runs of padding slots do not count
-    return (acc | (runend << 16)).to(torch.int32).reshape(-1), tile_dup
+    return ((acc << 8) | runend).to(torch.int32).reshape(-1), tile_dup
 
 
 @dataclass
