@@ -1163,6 +1163,9 @@ static int check_plan(const rgcn_plan_t* p) {
 // row size (v_mad_u32_u24), 32-bit offsets with the one-past-the-end padding row and the all-ones "beyond
 // the width" offset out of range; else 0 -> the kernels fall back to 64-bit pointers
 static unsigned buffer_bytes(int rows, int ld) {
+    // RGCN_FORCE_POINTER_GATHER=1: exercise the 64-bit pointer fallback on small inputs (tests)
+    const char* force = getenv("RGCN_FORCE_POINTER_GATHER");
+    if (force && force[0] == '1') return 0u;
     const size_t bytes = (size_t)rows * ld * sizeof(float);
     const size_t with_pad_row = bytes + (size_t)ld * sizeof(float);
     return (rows < (1 << 24) && with_pad_row < 0xFFFFFF00ull) ? (unsigned)bytes : 0u;
@@ -1378,7 +1381,12 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     if (workspace_bytes < need) return RGCN_ERR_WORKSPACE;
     const int KP = padded_width(din), NP = padded_width(dout);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, need, s);
+    // small graphs: fewer persistent workgroups (>= 16 chunks each), and only their slabs are cleared / summed
+    const int nblocks = plan->n_chunks / 16 < 1 ? 1 : (plan->n_chunks / 16 > kDwBlocks ? kDwBlocks : plan->n_chunks / 16);
+    const size_t slab_bytes = sizeof(float) * (size_t)(nblocks + plan->num_relations + 1) * kDwSlabsPer * KP * NP;
+    float* bias_slabs = (float*)workspace + dw_slab_floats(plan->num_relations, KP, NP);
+    hipError_t e = hipMemsetAsync(workspace, 0, slab_bytes, s);
+    if (e == hipSuccess) e = hipMemsetAsync(bias_slabs, 0, sizeof(float) * (size_t)nblocks * kDwSlabsPer * NP, s);
     if (e != hipSuccess) return (int)e;
     DwArgs a;
     a.rel_order = plan->rel_order;
@@ -1391,7 +1399,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.x = x;
     a.g = g;
     a.slabs = (float*)workspace;
-    a.bias_slabs = a.slabs + dw_slab_floats(plan->num_relations, KP, NP);
+    a.bias_slabs = bias_slabs;
     a.ldx = ldx;
     a.x_bytes = buffer_bytes(plan->n_nodes, ldx);
     a.g_bytes = buffer_bytes(plan->n_owned, ldg);
@@ -1403,10 +1411,10 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.tile = plan->tile;
     a.n_chunks = plan->n_chunks;
     a.num_rel = plan->num_relations;
-    st = dispatch_dw(KP, NP, a, kDwBlocks, s);
+    st = dispatch_dw(KP, NP, a, nblocks, s);
     if (st != RGCN_OK) return st;
     hipLaunchKernelGGL(rgcn_dw_reduce_kernel, dim3(plan->num_relations + 2, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs, a.bias_slabs,
-                       plan->rel_order, plan->chunk_rel, plan->n_chunks, kDwBlocks, plan->num_relations, KP, NP, din,
+                       plan->rel_order, plan->chunk_rel, plan->n_chunks, nblocks, plan->num_relations, KP, NP, din,
                        dout, d_weight, d_root, d_bias);
     return (int)hipGetLastError();
 }

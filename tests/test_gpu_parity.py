@@ -214,3 +214,23 @@ def test_frozen_params_and_override_contract(dev):
         ref = torch.sigmoid(O.rgcn_conv_loop(h, ei, et, src.rgcn2.weight.cpu().double(),
                                              src.rgcn2.root.cpu().double(), src.rgcn2.bias.cpu().double()))
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), **TOL)
+
+
+def test_pointer_gather_fallback_path(dev, monkeypatch):
+    """Matrices of 4 GiB and more (or >= 2^24 rows) cannot go through a buffer descriptor; the kernels then
+    gather through 64-bit pointers.  Forced here on a small input so the fallback is covered."""
+    monkeypatch.setenv("RGCN_FORCE_POINTER_GATHER", "1")
+    for din, dout in ((64, 64), (63, 16), (128, 32)):
+        n, e, r = 1200, 15000, 6
+        ei, et = O.synthetic_graph(n, e, r, seed=21)
+        w, root, bias = O.synthetic_params(r, din, dout, seed=5)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(n, din, generator=g)
+        dg = torch.randn(n, dout, generator=g)
+        ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+        out, dx, dw, dr, db = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg)
+        c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
+        assert_close(out, ref, c_out, "out")
+        assert_close(dx, gr["x"], c["x"], "d_x")
+        assert_close(dw, gr["weight"], c["weight"], "d_weight")
+        assert_close(dr, gr["root"], c["root"], "d_root")
