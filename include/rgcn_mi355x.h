@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 4
+#define RGCN_ABI_VERSION 5
 #define RGCN_CHUNK 64 /* edge slots per chunk == rows of one LDS ring slot */
 #define RGCN_MAX_WIDTH 128
 
@@ -68,7 +68,8 @@ typedef struct rgcn_plan {
     const int32_t* rel_order;  /* [n_chunks] chunk ids sorted by (relation, tile) */
     const int32_t* slot_src;   /* [n_chunks * 64] row to gather; padding = n_nodes (one past the last row) */
     const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */
-    const int32_t* slot_dstl;  /* [n_chunks * 64] row inside the tile, ascending inside a chunk; padding = tile */
+    const int32_t* slot_row;   /* [n_chunks * 64] row of the owned range the slot scatters into (tile * tile_size + row
+                                * in tile), ascending inside a 16-slot row tile; padding = n_owned */
     const int32_t* slot_acc;   /* [n_chunks * 64] forward run-sum metadata per slot: (accumulator row written) << 8
                                 * | (position 0..15 in the 16-slot MFMA row tile of the slot ending this slot's
                                 * run of equal destinations); the row is slot_dstl if the slot ends its run,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
@@ -28,7 +28,7 @@ class RgcnPlanStruct(C.Structure):
         ("tile", C.c_int32), ("n_tiles", C.c_int32), ("n_chunks", C.c_int32),
         ("tile_ptr", C.c_void_p), ("chunk_rel", C.c_void_p), ("chunk_cnt", C.c_void_p),
         ("chunk_tile", C.c_void_p), ("chunk_flags", C.c_void_p), ("rel_order", C.c_void_p), ("slot_src", C.c_void_p),
-        ("slot_w", C.c_void_p), ("slot_dstl", C.c_void_p), ("slot_acc", C.c_void_p),
+        ("slot_w", C.c_void_p), ("slot_row", C.c_void_p), ("slot_acc", C.c_void_p),
     ]
 
 
@@ -88,7 +88,7 @@ def plan_struct(plan) -> RgcnPlanStruct:
         plan.n_nodes, plan.n_owned, plan.num_relations, plan.tile, plan.n_tiles, plan.n_chunks,
         plan.tile_ptr.data_ptr(), plan.chunk_rel.data_ptr(), plan.chunk_cnt.data_ptr(),
         plan.chunk_tile.data_ptr(), plan.chunk_flags.data_ptr(), plan.rel_order.data_ptr(), plan.slot_src.data_ptr(),
-        plan.slot_w.data_ptr(), plan.slot_dstl.data_ptr(), plan.slot_acc.data_ptr())
+        plan.slot_w.data_ptr(), plan.slot_row.data_ptr(), plan.slot_acc.data_ptr())
 
 
 def _stream() -> int:

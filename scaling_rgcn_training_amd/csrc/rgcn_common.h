@@ -51,8 +51,10 @@ __device__ __forceinline__ void dma4(const void* gptr, void* lds_base) {
 // Same, through a buffer descriptor: address = rsrc base + voffset (32-bit, per lane); an offset beyond
 // num_records makes the hardware range check feed ZEROS, which is how padding rows and padding columns
 // are produced without a pointer select or 64-bit address arithmetic.
+// AUX: cache-policy bits of the load (0 default, 2 = nt: streamed data that is read once)
+template <int AUX = 0>
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, float* lds_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, 0, 0, AUX);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     // dword3 0x00020000: raw 32-bit data format (stride 0, offen addressing, range check on num_records)

@@ -45,6 +45,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 #ifndef RGCN_PRIO
 #define RGCN_PRIO 3
 #endif
+#ifndef RGCN_NT_H
+#define RGCN_NT_H 0   // cache policy of the wide dW kernel's H-row gather (probe: 2 = nt)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // weight pack
@@ -135,7 +138,7 @@ struct RowGather {
             else co = coff[i % V];
             if constexpr (BUF) {
                 const unsigned off = co == 0xFFFFFFF0u ? co : __umul24((unsigned)idx[i], row_bytes) + co;
-                dma16_buf(rsrc, off, dst);
+                dma16_buf<RGCN_NT_H>(rsrc, off, dst);
             } else {
                 const float* gp = (idx[i] < n_rows && co != 0xFFFFFFF0u)
                                       ? (const float*)((const char*)(base + (size_t)idx[i] * ld) + co) : g_zero16;
@@ -574,7 +577,7 @@ struct DwArgs {
     const int* chunk_tile;
     const int* slot_src;
     const float* slot_w;
-    const int* slot_dstl;
+    const int* slot_row;
     const float* x;
     const float* g;
     unsigned x_bytes, g_bytes;
@@ -770,14 +773,13 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
             const int kk = k < nch ? k : nch - 1;
             const int chunk = ldc(a.rel_order, i0 + kk);
             idx_h = a.slot_src[(size_t)chunk * kChunk + lane];
-            idx_g = a.slot_dstl[(size_t)chunk * kChunk + lane];
+            idx_g = a.slot_row[(size_t)chunk * kChunk + lane];
         };
         load_idx(knext);
         auto issue = [&](int k) {
             const int chunk = ldc(a.rel_order, i0 + k), buf = k % NBUF;
-            const int gi = idx_h < a.n_rows ? ldc(a.chunk_tile, chunk) * a.tile + idx_g : a.n_owned;
             gather_h.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idx_h, ringh + buf * kChunk * KP);
-            gather_g.issue(a.g, a.g_bytes, a.n_owned, a.ldg, gi, ringg + buf * kChunk * NP);
+            gather_g.issue(a.g, a.g_bytes, a.n_owned, a.ldg, idx_g, ringg + buf * kChunk * NP);
             dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
             knext += kProducerWaves;
             load_idx(knext);
@@ -943,8 +945,13 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
 #pragma unroll
                 for (int ia = 0; ia < NA; ++ia)
 #pragma unroll
-                    for (int jb = 0; jb < NB; ++jb)
+                    for (int jb = 0; jb < NB; ++jb) {
+                        if (RGCN_ABL & 1) {   // diagnostic build: no MFMA
+                            acc[ia][jb][0] += o.a4[ia >> 2][ia & 3] * bv[jb];
+                            continue;
+                        }
                         acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a4[ia >> 2][ia & 3], bv[jb], acc[ia][jb], 0, 0, 0);
+                    }
             };
             const int ngrp = (cnt + 15) >> 4;
             // this team's groups: g0, g0 + TEAMS, ...; the starting team alternates with the chunk so that
@@ -1002,44 +1009,16 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
         gather_g.init(lane, a.dout4);
         constexpr int OPS_ROWS = KP / 16 + NP / 16;             // row DMAs of one wave per chunk
         auto chunk_of = [&](int k) { return ldc(a.rel_order, i0 + (k < nch ? k : nch - 1)); };
-        auto issue_idx = [&](int k) {                           // wave 0 only: 2 ops
-            const int chunk = chunk_of(k);
+        // chunk ids for the NEXT step are fetched (scalar loads) during the current one
+        int c_rows = chunk_of(0), c_idx = chunk_of(2 * D);
+        auto issue_idx = [&](int k, int chunk) {                // wave 0 only: 2 ops
             dma4(a.slot_src + (size_t)chunk * kChunk + lane, idxh + (k % IR) * kChunk);
-            dma4(a.slot_dstl + (size_t)chunk * kChunk + lane, idxg + (k % IR) * kChunk);
+            dma4(a.slot_row + (size_t)chunk * kChunk + lane, idxg + (k % IR) * kChunk);
         };
-        auto issue_rows = [&](int k) {                          // OPS_ROWS ops (+1 on wave 0)
-            const int chunk = chunk_of(k), buf = k % NBUF;
-            const int* ih = idxh + (k % IR) * kChunk;
-            const int* ig = idxg + (k % IR) * kChunk;
-            gather_h.issue_quarter(a.x, a.x_bytes, a.n_rows, a.ldx, ih, ringh + buf * kChunk * KP, pw);
-            // G row = first row of the chunk's tile + row in tile; padding slots (src == n_rows) -> one past the end
-            {
-                constexpr int RPI = RowGather<NP, kLinear, BUF>::RPI, QOPS = RowGather<NP, kLinear, BUF>::NOPS / 4;
-                const int base_row = ldc(a.chunk_tile, chunk) * a.tile;
-                int* gi = (int*)(wring) + 0;  // (unused; indices are combined in registers below)
-                (void)gi;
-                int grow[QOPS];
-#pragma unroll
-                for (int i = 0; i < QOPS; ++i) {
-                    const int r = 16 * pw + i * RPI + gather_g.rsub;
-                    grow[i] = ih[r] < a.n_rows ? base_row + ig[r] : a.n_owned;
-                }
-                const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.g, a.g_bytes);
-                const unsigned row_bytes = (unsigned)a.ldg * 4u;
-#pragma unroll
-                for (int i = 0; i < QOPS; ++i) {
-                    float* dst = ringg + buf * kChunk * NP + (16 * pw + i * RPI) * NP;
-                    const unsigned co = gather_g.coff[0];
-                    if constexpr (BUF) {
-                        const unsigned off = co == 0xFFFFFFF0u ? co : __umul24((unsigned)grow[i], row_bytes) + co;
-                        dma16_buf(rsrc, off, dst);
-                    } else {
-                        const float* gp = (grow[i] < a.n_owned && co != 0xFFFFFFF0u)
-                                              ? (const float*)((const char*)(a.g + (size_t)grow[i] * a.ldg) + co) : g_zero16;
-                        dma16(gp, dst);
-                    }
-                }
-            }
+        auto issue_rows = [&](int k, int chunk) {               // OPS_ROWS ops (+1 on wave 0)
+            const int buf = k % NBUF;
+            gather_h.issue_quarter(a.x, a.x_bytes, a.n_rows, a.ldx, idxh + (k % IR) * kChunk, ringh + buf * kChunk * KP, pw);
+            gather_g.issue_quarter(a.g, a.g_bytes, a.n_owned, a.ldg, idxg + (k % IR) * kChunk, ringg + buf * kChunk * NP, pw);
             if (pw == 0) dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
         };
         auto wait_ahead = [&]() {       // everything but the (D-1) youngest iterations' operations has landed
@@ -1049,13 +1028,16 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
         // step s = { wave 0: index vectors of chunk s + 2D ; every wave: its quarter of chunk s } -- the same
         // operation count for every s, which is what makes wait_ahead() exact from the first iteration on
         auto step = [&](int sidx) {
-            if (pw == 0) issue_idx(sidx + 2 * D);
-            issue_rows(sidx);
+            const int cr = c_rows, ci = c_idx;
+            c_rows = chunk_of(sidx + 1);
+            c_idx = chunk_of(sidx + 1 + 2 * D);
+            if (pw == 0) issue_idx(sidx + 2 * D, ci);
+            issue_rows(sidx, cr);
         };
         // prologue: index vectors of chunks 0 .. 2D-1 up front, then steps 0 .. D-1
         if (pw == 0) {
 #pragma unroll
-            for (int k = 0; k < 2 * D; ++k) issue_idx(k);
+            for (int k = 0; k < 2 * D; ++k) issue_idx(k, chunk_of(k));
             wait_vmcnt<0>();
         }
         wg_barrier();
@@ -1151,7 +1133,7 @@ static int check_plan(const rgcn_plan_t* p) {
     if (p == nullptr) return RGCN_ERR_NULL;
     if (!p->tile_ptr || !p->chunk_rel || !p->chunk_cnt || !p->chunk_tile || !p->chunk_flags || !p->rel_order ||
         !p->slot_src ||
-        !p->slot_w || !p->slot_dstl || !p->slot_acc)
+        !p->slot_w || !p->slot_row || !p->slot_acc)
         return RGCN_ERR_NULL;
     if (p->n_nodes <= 0 || p->n_owned <= 0 || p->num_relations <= 0 || p->tile <= 0 || (p->tile % 16) != 0 || p->tile > 32768 ||
         p->n_tiles <= 0 || p->n_chunks < p->n_tiles || (long)p->n_tiles * p->tile < p->n_owned)
@@ -1395,7 +1377,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.chunk_tile = plan->chunk_tile;
     a.slot_src = plan->slot_src;
     a.slot_w = plan->slot_w;
-    a.slot_dstl = plan->slot_dstl;
+    a.slot_row = plan->slot_row;
     a.x = x;
     a.g = g;
     a.slabs = (float*)workspace;

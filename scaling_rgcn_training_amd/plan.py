@@ -17,7 +17,8 @@ Layout (all int32 / float32, device resident):
 * per slot: ``slot_src`` (row to gather; padding = ``n_nodes``, one past the last row, which a buffer-descriptor
   gather turns into zeros by its range check), ``slot_w`` (edge weight
   ``1 / max(1, c[dst, rel])`` for ``aggr='mean'``, 0 = padding), ``slot_dstl`` (row inside the tile,
-  ``tile`` = padding: the kernels keep one dummy accumulator row there); inside a chunk the slots are
+  ``tile`` = padding; host-side only) and ``slot_row`` (the same as a row of the owned range, padding = one past the
+  end: what the dW kernel gathers the upstream gradient by); inside a chunk the slots are
   sorted by ``slot_dstl``, which the forward kernel's run-sum relies on; ``slot_acc`` packs what that
   run-sum needs per slot (accumulator row << 8 | run-end position, see ``run_metadata``);
   duplicate (src, dst, relation) triples share ONE slot whose weight is the sum of theirs;
@@ -57,7 +58,8 @@ class TilePlan:
     rel_order: Tensor     # int32 [n_chunks]
     slot_src: Tensor      # int32 [n_chunks * CHUNK]
     slot_w: Tensor        # float32 [n_chunks * CHUNK]
-    slot_dstl: Tensor     # int32 [n_chunks * CHUNK]
+    slot_dstl: Tensor     # int32 [n_chunks * CHUNK]  row inside the tile (padding: tile)
+    slot_row: Tensor      # int32 [n_chunks * CHUNK]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
     slot_acc: Tensor      # int32 [n_chunks * CHUNK]  accumulator row << 8 | run-end position
     _keep: tuple = field(default=(), repr=False)
 
@@ -72,7 +74,7 @@ class TilePlan:
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (
             self.tile_ptr, self.chunk_rel, self.chunk_cnt, self.chunk_tile, self.chunk_flags, self.rel_order,
-            self.slot_src, self.slot_w, self.slot_dstl, self.slot_acc))
+            self.slot_src, self.slot_w, self.slot_row, self.slot_acc))
 
 
 def edge_weights(src: Tensor, dst: Tensor, rel: Tensor, num_relations: int, aggr: str = "mean") -> Tensor:
@@ -168,6 +170,10 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     chunk_flags = (tile_dup.view(-1, CHUNK // g16).to(torch.int32)
                    * (2 ** torch.arange(CHUNK // g16, device=dev, dtype=torch.int32))).sum(1).to(torch.int32)
     grp_of_chunk = torch.repeat_interleave(torch.arange(n_groups, device=dev), gch)
+    # the dW kernel gathers the upstream-gradient row of every slot: its index in the owned range
+    tile_of_slot = torch.repeat_interleave((gvals[grp_of_chunk] // r1).to(torch.int32), CHUNK)
+    slot_row = torch.where(slot_dstl < tile, tile_of_slot * tile + slot_dstl,
+                           torch.full_like(slot_dstl, n_own))
     idx_in_grp = torch.arange(n_chunks, device=dev) - chunk_base[grp_of_chunk]
     # slots of the chunk's used row tiles (a multiple of 16; padding sits at the end of every tile)
     chunk_cnt = (torch.clamp(gnt[grp_of_chunk] - idx_in_grp * (CHUNK // g16), max=CHUNK // g16) * g16).to(torch.int32)
@@ -183,7 +189,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     num_relations=num_relations, tile=tile, n_tiles=n_tiles, n_chunks=n_chunks,
                     n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
-                    slot_dstl=slot_dstl, slot_acc=slot_acc, chunk_flags=chunk_flags)
+                    slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags)
 
 
 ROWS_PER_MFMA_TILE = 16

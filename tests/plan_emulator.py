@@ -11,11 +11,9 @@ from scaling_rgcn_training_amd.plan import CHUNK
 def _slots(plan):
     src = plan.slot_src.cpu().numpy().astype(np.int64)
     w = plan.slot_w.cpu().numpy().astype(np.float64)
-    dstl = plan.slot_dstl.cpu().numpy().astype(np.int64)
     rel = np.repeat(plan.chunk_rel.cpu().numpy().astype(np.int64), CHUNK)
-    tile = np.repeat(plan.chunk_tile.cpu().numpy().astype(np.int64), CHUNK)
     valid = src < plan.n_nodes
-    node = tile * plan.tile + dstl  # local to node_begin
+    node = plan.slot_row.cpu().numpy().astype(np.int64)  # row of the owned range (local to node_begin)
     return src, w, rel, node, valid
 
 

@@ -52,6 +52,9 @@ def _check_invariants(plan, n_real_edges):
             j = int(rend[t, i])
             assert i <= j < 16 and torch.all(d16[t, i:j + 1] == d16[t, i]) and (j == 15 or d16[t, j + 1] != d16[t, i])
             assert acc[t, i] == (d16[t, i] if i == j else plan.tile)
+    tile_of_slot = torch.repeat_interleave(plan.chunk_tile.long(), c).view(-1, 16)
+    row = plan.slot_row.view(-1, 16).long()
+    assert torch.all(row[valid] == (tile_of_slot * plan.tile + dl)[valid]) and torch.all(row[~valid] == plan.n_owned)
     tp = plan.tile_ptr.long()
     assert tp[0] == 0 and tp[-1] == plan.n_chunks and torch.all(tp[1:] > tp[:-1])
     for t in range(plan.n_tiles):                                   # tile-major, rel ascending, root last
