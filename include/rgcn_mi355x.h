@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 5
+#define RGCN_ABI_VERSION 6
 #define RGCN_CHUNK 64 /* edge slots per chunk == rows of one LDS ring slot */
 #define RGCN_MAX_WIDTH 128
 
@@ -70,10 +70,10 @@ typedef struct rgcn_plan {
     const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */
     const int32_t* slot_row;   /* [n_chunks * 64] row of the owned range the slot scatters into (tile * tile_size + row
                                 * in tile), ascending inside a 16-slot row tile; padding = n_owned */
-    const int32_t* slot_acc;   /* [n_chunks * 64] forward run-sum metadata per slot: (accumulator row written) << 8
-                                * | (position 0..15 in the 16-slot MFMA row tile of the slot ending this slot's
-                                * run of equal destinations); the row is slot_dstl if the slot ends its run,
-                                * else `tile` (dummy row) */
+    const int32_t* slot_acc;   /* [n_chunks * 64] forward run-sum metadata per slot: (position 0..15 in the 16-slot
+                                * MFMA row tile of the slot ending this slot's run of equal destinations) << 24 |
+                                * (accumulator row written); the row is the slot's row in the tile if the slot
+                                * ends its run, else `tile` (dummy row) */
 } rgcn_plan_t;
 
 int rgcn_abi_version(void);

@@ -213,6 +213,10 @@ struct TileArgs {
     int dbg;  // diagnostic ablations (RGCN_DEBUG_MODE env): 1 skip MFMA+accumulate, 2 skip DMA, 4 skip B loads
 };
 
+// accumulator row stride of the tile kernel's LDS tile (floats)
+template <int NP>
+constexpr int kAccStride = NP + 4;
+
 template <int KP, int NP, int NBUF, bool BUF>
 __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a) {
     constexpr int KT = KP / 16, NT = NP / 16;
@@ -221,10 +225,12 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
     constexpr int CW = NT < 4 ? NT : 4;          // consumer waves that own output column slices
     constexpr int SL = NT < 4 ? 1 : NT / 4;      // column slices per consumer wave
     constexpr int LPR = KP / 4;
+    constexpr int LDO = kAccStride<NP>;          // accumulator row stride: NP + 4 floats, so that the 16 rows one
+                                                 // ds_read/write_b128 touches start in different banks
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* out_lds = lds;                         // [tile][NP]
-    float* ring = lds + (a.tile + 1) * NP;        // [NBUF][64][KP]  (row `tile` of out_lds: dummy)
+    float* out_lds = lds;                         // [tile + 1][LDO]  (row `tile`: dummy)
+    float* ring = lds + (a.tile + 1) * LDO;       // [NBUF][64][KP]
     float* wring = ring + NBUF * kChunk * KP;     // [NBUF][64]
     int* dring = (int*)(wring + NBUF * kChunk);   // [NBUF][64]
 
@@ -235,8 +241,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
     const int c0 = ldc(a.tile_ptr, tile);
     const int nch = ldc(a.tile_ptr, tile + 1) - c0;
 
-    for (int i = tid; i < (a.tile + 1) * NP; i += kThreads) {
-        const int col = i % NP;
+    for (int i = tid; i < (a.tile + 1) * LDO; i += kThreads) {
+        const int col = i % LDO;
         out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
     }
 
@@ -258,7 +264,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         const bool active = cwv < CW;
         const int cw = cwv;
         const int rowl = lane & 15, kq = lane >> 4;
-        const unsigned lane_col_bytes = (unsigned)(16 * cw + rowl) * 4u;   // this lane's column in slice 0
+        const unsigned lane_col_bytes = (unsigned)(16 * cw + rowl) * 4u;   // this lane's column in slice 0 (Y layout)
+        const unsigned lane_col4_bytes = (unsigned)(16 * cw + 4 * kq) * 4u; // its four columns in the Y^T layout
         const f32x4* wp4 = (const f32x4*)a.wp;
         f32x4 bcur[SL][KT], bnext[SL][KT];
         int rel_cur = ldc(a.chunk_rel, c0);
@@ -323,27 +330,48 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             // instructions compete with the fp32 MFMAs for the same SIMD pipe, so none are spent on it here.
             struct Ops {
                 f32x4 av[KT];
-                f32x4 w4;   // weights of rows 4*kq + i (the rows whose MFMA results this lane holds)
-                i32x4 d4;   // their run metadata from the plan: accumulator row | run-end position << 16
+                f32x4 w4;   // Y layout: weights of rows 4*kq + i (the rows whose MFMA results this lane holds)
+                i32x4 d4;   //           their run metadata from the plan: run-end position << 24 | accumulator row
+                float w1;   // Y^T layout: weight and metadata of row `rowl`
+                int d1;
             };
             // per-tile state carried between the pipeline stages below
             struct Tile {
                 f32x4 y[SL];      // H W_r of the tile (main MFMA result); after stage B: one addend of the update
                 f32x4 z[SL];      // after stage B: the other addend (old accumulator contents [+ run sums])
-                float* dst[4];    // accumulator rows this lane updates
+                f32x4 old[SL];    // Y^T path: accumulator contents (y, z = the two MFMA chains)
+                float* dst[4];    // accumulator rows this lane updates (Y^T path: dst[0] only)
             };
-            auto load_ops = [&](Ops& o, int rt) {
+            auto load_ops = [&](Ops& o, int rt, auto tr_c) {
                 const int row = rt * 16 + rowl;
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
                     o.av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
                 }
-                o.w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
-                o.d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
+                if constexpr (decltype(tr_c)::value) {
+                    o.w1 = wb[rt * 16 + rowl];
+                    o.d1 = db[rt * 16 + rowl];
+                } else {
+                    o.w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
+                    o.d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
+                }
             };
-            // stage A: y = H_tile . W_r (16 MFMAs per column slice, two independent chains)
-            auto stage_a = [&](const Ops& o, Tile& t) {
+            // accumulator row (low 24 bits of the plan's metadata word) -> LDS address of this lane's column(s):
+            // one v_mad_u32_u24 (it ignores the run-end byte on top by itself)
+            auto acc_ptr = [&](int d, unsigned col_bytes) -> float* {
+                return (float*)((char*)out_lds + (__umul24((unsigned)d, (unsigned)(LDO * 4)) + col_bytes));
+            };
+
+            // ===== chunks WITHOUT repeated destinations inside any row tile (nearly all of them: the plan spreads
+            // a run over different tiles whenever it can): the Y^T path ======================================
+            // Y^T = W_r^T . H_tile^T -- the same two registers per MFMA as Y = H W, operands swapped -- leaves a
+            // lane with FOUR CONSECUTIVE COLUMNS of ONE row, so its accumulator update is one ds_read_b128, four
+            // packed FMAs and one ds_write_b128.  Every vector instruction next to an fp32 MFMA costs its full
+            // 4+ issue cycles ON TOP of the MFMA time, plus ~10 cycles per MFMA->VALU->MFMA switch
+            // (tools/probes/mfma_f32_overlap.hip: only LDS traffic hides under v_mfma_f32_16x16x4_f32); the Y
+            // layout spends 4 b32 reads + 4 b32 writes + 4 addresses + 6 more VALU per slice.
+            auto stage_a_t = [&](const Ops& o, Tile& t) {
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -353,6 +381,37 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                             acc0 += o.av[j];
                             continue;
                         }
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][0], o.av[j][0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][1], o.av[j][1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][2], o.av[j][2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][3], o.av[j][3], acc1, 0, 0, 0);
+                    }
+                    t.y[s] = acc0;      // the two chains are folded in stage C's FMAs
+                    t.z[s] = acc1;
+                }
+            };
+            auto stage_b_t = [&](const Ops& o, Tile& t) {     // old accumulator contents (after tile t-1's store)
+                t.dst[0] = acc_ptr(o.d1, lane_col4_bytes);
+#pragma unroll
+                for (int s = 0; s < SL; ++s) t.old[s] = *(const f32x4*)(t.dst[0] + 16 * CW * s);
+            };
+            auto stage_c_t = [&](const Ops& o, Tile& t) {     // acc_new = old + w * chain0 + w * chain1
+#pragma unroll
+                for (int s = 0; s < SL; ++s) {
+                    f32x4 v = t.y[s] * o.w1 + t.old[s];
+                    v = t.z[s] * o.w1 + v;
+                    *(f32x4*)(t.dst[0] + 16 * CW * s) = v;
+                }
+            };
+
+            // ===== chunks with a repeated destination in some row tile: the Y path ===========================
+            // stage A: y = H_tile . W_r (16 MFMAs per column slice, two independent chains)
+            auto stage_a = [&](const Ops& o, Tile& t) {
+#pragma unroll
+                for (int s = 0; s < SL; ++s) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) {
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][0], bcur[s][j][0], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][1], bcur[s][j][1], acc1, 0, 0, 0);
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[j][2], bcur[s][j][2], acc0, 0, 0, 0);
@@ -366,22 +425,12 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             // pairwise distinct destinations inside the tile.  Y's accumulator registers are already in
             // B-operand layout for MFMA step i with k = 4*k' + i: no data movement.  The accumulator reads
             // of stage C are issued here (after the previous tile's stage-C writes in program order).
-            // byte offset of accumulator row (d >> 8) in the LDS tile, plus this lane's column: one bit-field
-            // insert when a row is 256 B (NP = 64), shift + insert otherwise
-            auto acc_ptr = [&](int d) -> float* {
-                constexpr unsigned kRowMask = 0xFFFFFF00u;
-                unsigned off;
-                if constexpr (NP == 64) off = ((unsigned)d & kRowMask) | lane_col_bytes;
-                else off = (((unsigned)d >> 8) * (NP * 4)) + lane_col_bytes;
-                return (float*)((char*)out_lds + off);
-            };
             auto stage_b = [&](const Ops& o, Tile& t, bool dup) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t.dst[i] = acc_ptr(o.d4[i]);
+                for (int i = 0; i < 4; ++i) t.dst[i] = acc_ptr(o.d4[i], lane_col_bytes);
                 if (!dup) {
-                    // no destination repeats inside this row tile (the plan spreads a run over different
-                    // tiles whenever it can): every row ends its own run, P would be diag(w) -- no product,
-                    // and the accumulate is one fused multiply-add per element: acc_new = y * w + acc_old
+                    // no destination repeats inside THIS row tile: every row ends its own run, P would be
+                    // diag(w) -- no product: acc_new = y * w + acc_old
 #pragma unroll
                     for (int s = 0; s < SL; ++s) {
                         f32x4 old;
@@ -395,9 +444,9 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                 float pm[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    // row 4*kq + i belongs to the run that ends at tile row (d & 0xFF); this lane supplies
+                    // row 4*kq + i belongs to the run that ends at tile row (d >> 24); this lane supplies
                     // P[m = rowl][k = 4*kq + i]
-                    pm[i] = ((unsigned)o.d4[i] & 0xFFu) == (unsigned)rowl ? o.w4[i] : 0.f;
+                    pm[i] = ((unsigned)o.d4[i] >> 24) == (unsigned)rowl ? o.w4[i] : 0.f;
                 }
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
@@ -412,7 +461,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                     t.y[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], t.y[s][3], z1, 0, 0, 0);
                 }
             };
-            // stage C: write back acc_new = z + y (both paths leave the two addends there); this wave owns
+            // stage C: write back acc_new = z + y (both branches leave the two addends there); this wave owns
             // these columns and the rows written by one instruction are pairwise distinct: plain stores
             auto stage_c = [&](Tile& t) {
 #pragma unroll
@@ -422,46 +471,54 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                     for (int i = 0; i < 4; ++i) t.dst[i][16 * CW * s] = v[i];
                 }
             };
-            // One straight-line block per tile count (1..4) so hipcc can interleave freely.  Software
+            // One straight-line block per tile count (1..4) and path, so hipcc can interleave freely.  Software
             // pipeline: A(t+1) is issued before the tail of tile t, and stage C runs a further step behind,
-            // so the VALU / LDS work of one tile sits in the shadow of the next tiles' MFMAs instead of
-            // idling the matrix pipe (one MFMA-issuing wave per SIMD: nothing else would fill it).
-            auto consume = [&](auto nrt_c) {
+            // so the VALU / LDS work of one tile sits behind the next tiles' MFMAs in program order and its LDS
+            // round trips are hidden.
+            auto consume = [&](auto nrt_c, auto tr_c) {
                 constexpr int NRT = decltype(nrt_c)::value;
+                constexpr bool TR = decltype(tr_c)::value;
                 Ops ops[NRT];
                 Tile tl[NRT];
                 // LDS reads of tile t+1 are issued BEFORE the MFMAs of tile t and pinned there with
                 // sched_barrier: left alone, hipcc sinks every ds_read_b128 to just in front of the four
                 // MFMAs that use it and waits lgkmcnt(0) -- 16 exposed LDS round trips per chunk.
-                load_ops(ops[0], 0);
+                load_ops(ops[0], 0, tr_c);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int step = 0; step < NRT + 2; ++step) {
                     if (step + 1 < NRT) {
-                        load_ops(ops[step + 1], step + 1);
+                        load_ops(ops[step + 1], step + 1, tr_c);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (step < NRT) stage_a(ops[step], tl[step]);
-                    if (step >= 2) stage_c(tl[step - 2]);
-                    if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1], (flags >> (step - 1)) & 1);
+                    if constexpr (TR) {
+                        if (step < NRT) stage_a_t(ops[step], tl[step]);
+                        if (step >= 2) stage_c_t(ops[step - 2], tl[step - 2]);
+                        if (step >= 1 && step - 1 < NRT) stage_b_t(ops[step - 1], tl[step - 1]);
+                    } else {
+                        if (step < NRT) stage_a(ops[step], tl[step]);
+                        if (step >= 2) stage_c(tl[step - 2]);
+                        if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1], (flags >> (step - 1)) & 1);
+                    }
                 }
-                // ask the scheduler for MFMA / VALU / LDS interleaving: an MFMA holds the issue port for 8
-                // of its 32 cycles, the other 24 take ~5 single-issue instructions of the same wave
-#if RGCN_SGB
-#pragma unroll
-                for (int i = 0; i < NRT * SL * (4 * KT + 4); ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, RGCN_SGB, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);   // 1 DS
-                }
-#endif
             };
-            switch (nrt) {
-                case 1: consume(std::integral_constant<int, 1>{}); break;
-                case 2: consume(std::integral_constant<int, 2>{}); break;
-                case 3: consume(std::integral_constant<int, 3>{}); break;
-                case 4: consume(std::integral_constant<int, 4>{}); break;
-                default: break;
+            using std::integral_constant;
+            if (flags == 0) {
+                switch (nrt) {
+                    case 1: consume(integral_constant<int, 1>{}, std::true_type{}); break;
+                    case 2: consume(integral_constant<int, 2>{}, std::true_type{}); break;
+                    case 3: consume(integral_constant<int, 3>{}, std::true_type{}); break;
+                    case 4: consume(integral_constant<int, 4>{}, std::true_type{}); break;
+                    default: break;
+                }
+            } else {
+                switch (nrt) {
+                    case 1: consume(integral_constant<int, 1>{}, std::false_type{}); break;
+                    case 2: consume(integral_constant<int, 2>{}, std::false_type{}); break;
+                    case 3: consume(integral_constant<int, 3>{}, std::false_type{}); break;
+                    case 4: consume(integral_constant<int, 4>{}, std::false_type{}); break;
+                    default: break;
+                }
             }
             STAMP(t2);
             if (swap_b) {
@@ -559,7 +616,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
     const int o4 = (a.dout + 3) >> 2;
     for (int i = tid; i < rows * o4; i += kThreads) {
         const int r = i / o4, c4 = i - r * o4;
-        const f32x4 v = *(const f32x4*)(out_lds + r * NP + c4 * 4);
+        const f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
         *(f32x4*)(a.out + (size_t)(row0 + r) * a.ldo + c4 * 4) = v;
     }
 }
@@ -1172,7 +1229,7 @@ static int launch_tile_nbuf(const TileArgs& a, int n_tiles, size_t lds, hipStrea
 template <int KP, int NP>
 static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
     auto bytes = [&](int nbuf) {
-        return sizeof(float) * ((size_t)(a.tile + 1) * NP + (size_t)nbuf * kChunk * (KP + 2));
+        return sizeof(float) * ((size_t)(a.tile + 1) * kAccStride<NP> + (size_t)nbuf * kChunk * (KP + 2));
     };
     if (KP < 128 && bytes(4) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 4>(a, n_tiles, bytes(4), stream);
     if (KP < 128 && bytes(3) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 3>(a, n_tiles, bytes(3), stream);

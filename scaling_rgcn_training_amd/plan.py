@@ -20,7 +20,7 @@ Layout (all int32 / float32, device resident):
   ``tile`` = padding; host-side only) and ``slot_row`` (the same as a row of the owned range, padding = one past the
   end: what the dW kernel gathers the upstream gradient by); inside a chunk the slots are
   sorted by ``slot_dstl``, which the forward kernel's run-sum relies on; ``slot_acc`` packs what that
-  run-sum needs per slot (accumulator row << 8 | run-end position, see ``run_metadata``);
+  run-sum needs per slot (run-end position << 24 | accumulator row, see ``run_metadata``);
   duplicate (src, dst, relation) triples share ONE slot whose weight is the sum of theirs;
 * per chunk: ``chunk_rel``, ``chunk_cnt`` (slots of the used 16-slot row tiles), ``chunk_tile``, ``chunk_flags``; ``tile_ptr`` gives the tile-major
   chunk ranges (forward / dX kernels) and ``rel_order`` the relation-major order (dW kernel).
@@ -60,7 +60,7 @@ class TilePlan:
     slot_w: Tensor        # float32 [n_chunks * CHUNK]
     slot_dstl: Tensor     # int32 [n_chunks * CHUNK]  row inside the tile (padding: tile)
     slot_row: Tensor      # int32 [n_chunks * CHUNK]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
-    slot_acc: Tensor      # int32 [n_chunks * CHUNK]  accumulator row << 8 | run-end position
+    slot_acc: Tensor      # int32 [n_chunks * CHUNK]  run-end position << 24 | accumulator row
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -194,6 +194,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
 
 ROWS_PER_MFMA_TILE = 16
 LDS_BYTES = 160 * 1024
+ACC_PAD = 4    # floats of padding per accumulator row in the tile kernel's LDS tile (bank spread)
 
 
 def padded_width(w: int) -> int:
@@ -204,7 +205,7 @@ def padded_width(w: int) -> int:
 def choose_tile(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int,
                 min_ring: int = 3) -> int:
     """Output nodes per tile for a layer.  Both directions share the tile (forward: accumulator width =
-    out, dX: = in), so it is bounded by the wider side: (tile + 1) * pad(width) * 4 B of accumulator plus
+    out, dX: = in), so it is bounded by the wider side: (tile + 1) * (pad(width) + 4) * 4 B of accumulator plus
     ``min_ring`` DMA ring slots of 64 * (pad(other width) + 2) * 4 B must fit the 160 KiB LDS.
     Within that bound the tile is picked so that the expected (tile, relation) group -- tile * E / (N * R')
     edges, roughly Poisson -- fills its 64-slot chunks best: every chunk costs a workgroup barrier and a
@@ -213,8 +214,8 @@ def choose_tile(n_nodes: int, n_edges: int, num_relations: int, in_channels: int
     kp, np_ = padded_width(in_channels), padded_width(out_channels)
 
     def fits(t):
-        fwd = (t + 1) * np_ * 4 + min_ring * CHUNK * (kp + 2) * 4
-        bwd = (t + 1) * kp * 4 + min_ring * CHUNK * (np_ + 2) * 4
+        fwd = (t + 1) * (np_ + ACC_PAD) * 4 + min_ring * CHUNK * (kp + 2) * 4
+        bwd = (t + 1) * (kp + ACC_PAD) * 4 + min_ring * CHUNK * (np_ + 2) * 4
         return max(fwd, bwd) <= LDS_BYTES
 
     cands = [t for t in range(64, 513, 32) if fits(t)] or [64]
@@ -241,11 +242,11 @@ def run_metadata(slot_dstl: Tensor, tile: int):
     """Per slot, for the forward kernel's run-sum (csrc/rgcn_kernels.hip stage B/C), precomputed here so
     the kernel spends no vector instructions on it: inside every 16-slot MFMA row tile, slots with equal
     destination are adjacent (tiles are sorted by destination) and form a RUN; the run's sum is written by
-    its LAST slot only.  Returns (slot_acc, tile_dup).  slot_acc = (accumulator row the slot writes) << 8 |
-    (position 0..15 inside the row tile of the slot that ends this slot's run).  The accumulator row is the
+    its LAST slot only.  Returns (slot_acc, tile_dup).  slot_acc = (position 0..15 inside the row tile of the
+    slot that ends this slot's run) << 24 | (accumulator row the slot writes).  The accumulator row is the
     slot's destination if it ends a run, else the dummy row ``tile`` (padding slots carry destination ``tile``
-    already); shifted by 8 it IS the byte offset of that row in a 64-float-wide LDS accumulator, so the kernel
-    forms an address with one bit-field insert.
+    already); it sits in the low 24 bits so that the kernel forms the LDS address with one 24-bit
+    multiply-add, which ignores the top byte by itself.
     tile_dup[t]: row tile t contains a run longer than one slot (needs the run-sum product)."""
     g = ROWS_PER_MFMA_TILE
     d = slot_dstl.view(-1, g).to(torch.int64)
@@ -256,7 +257,7 @@ def run_metadata(slot_dstl: Tensor, tile: int):
     runend = torch.flip(torch.cummin(torch.flip(endpos, [1]), dim=1).values, [1])
     acc = torch.where(is_end, d, torch.full_like(d, tile))
     tile_dup = ((~is_end) & (d != tile)).any(dim=1)     # runs of padding slots do not count
-    return ((acc << 8) | runend).to(torch.int32).reshape(-1), tile_dup
+    return ((runend << 24) | acc).to(torch.int32).reshape(-1), tile_dup
 
 
 @dataclass

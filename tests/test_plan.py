@@ -44,8 +44,8 @@ def _check_invariants(plan, n_real_edges):
     assert torch.equal(flags, dup)
     # run metadata: inside each 16-slot row tile, exactly the LAST slot of a run of equal destinations
     # carries that destination, all others the dummy row; every slot points at its run's last slot
-    acc = (plan.slot_acc >> 8).view(-1, 16).long()
-    rend = (plan.slot_acc & 0xFF).view(-1, 16).long()
+    acc = (plan.slot_acc & 0xFFFFFF).view(-1, 16).long()
+    rend = (plan.slot_acc >> 24).view(-1, 16).long()
     d16 = plan.slot_dstl.view(-1, 16).long()
     for t in range(min(acc.shape[0], 400)):
         for i in range(16):
