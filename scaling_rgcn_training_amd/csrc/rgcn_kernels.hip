@@ -487,19 +487,27 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int step = 0; step < NRT + 2; ++step) {
+                    if constexpr (TR) {
+                        // per tile ONE group of vector instructions (store of tile t-1, address + accumulator read
+                        // of tile t) in front of tile t's 16 MFMAs: the read has the whole MFMA block to land, and
+                        // the MFMA->VALU->MFMA switch is paid once.  Store(t-1) precedes read(t) in program order:
+                        // consecutive tiles may hit the same accumulator row.
+                        if (step > NRT) continue;
+                        if (step + 1 < NRT) load_ops(ops[step + 1], step + 1, tr_c);
+                        if (step >= 1) stage_c_t(ops[step - 1], tl[step - 1]);
+                        if (step < NRT) stage_b_t(ops[step], tl[step]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (step < NRT) stage_a_t(ops[step], tl[step]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
                     if (step + 1 < NRT) {
                         load_ops(ops[step + 1], step + 1, tr_c);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (TR) {
-                        if (step < NRT) stage_a_t(ops[step], tl[step]);
-                        if (step >= 2) stage_c_t(ops[step - 2], tl[step - 2]);
-                        if (step >= 1 && step - 1 < NRT) stage_b_t(ops[step - 1], tl[step - 1]);
-                    } else {
-                        if (step < NRT) stage_a(ops[step], tl[step]);
-                        if (step >= 2) stage_c(tl[step - 2]);
-                        if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1], (flags >> (step - 1)) & 1);
-                    }
+                    if (step < NRT) stage_a(ops[step], tl[step]);
+                    if (step >= 2) stage_c(tl[step - 2]);
+                    if (step >= 1 && step - 1 < NRT) stage_b(ops[step - 1], tl[step - 1], (flags >> (step - 1)) & 1);
                 }
             };
             using std::integral_constant;
