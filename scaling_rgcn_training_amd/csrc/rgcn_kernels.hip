@@ -108,15 +108,20 @@ struct RowGather {
     static constexpr int NOPS = 64 / RPI;   // DMA instructions per chunk
     static constexpr int V = RPI >= 16 ? 1 : 16 / RPI;
     unsigned coff[V];   // byte offset of the 16-B column chunk this lane fetches (0xFFFFFFF0: beyond the width)
+    unsigned rowb[V];   // BUF: bytes per row, or 0 where coff is the out-of-range marker -- so that
+                        // offset = idx * rowb + coff is ONE v_mad_u32_u24 per DMA with no select behind it
     int rsub;
+    int perm_addr;      // ds_bpermute address of chunk row `rsub` (further rows: immediate offsets)
 
-    __device__ __forceinline__ void init(int lane, int n4) {
+    __device__ __forceinline__ void init(int lane, int n4, int ld) {
         rsub = lane / LPR;
+        perm_addr = rsub * 4;
         const int p = lane % LPR;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             const int c = p ^ swizzle<MODE, LPR>(v * RPI + rsub);   // which 16-B column chunk lands at position p
             coff[v] = c < n4 ? (unsigned)c * 16u : 0xFFFFFFF0u;
+            rowb[v] = c < n4 ? (unsigned)ld * 4u : 0u;
         }
     }
 
@@ -129,15 +134,19 @@ struct RowGather {
 #pragma unroll
         for (int i = 0; i < QOPS; ++i) idx[i] = idx_lds[16 * pw + i * RPI + rsub];
         const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
-        const unsigned row_bytes = (unsigned)ld * 4u;
 #pragma unroll
         for (int i = 0; i < QOPS; ++i) {
             float* dst = slot_base + (16 * pw + i * RPI) * W;
-            unsigned co;
-            if constexpr (V >= 4) co = coff[(pw * QOPS + i) % V];   // pw-dependent variant (uniform select)
-            else co = coff[i % V];
+            unsigned co, rb;
+            if constexpr (V >= 4) {   // pw-dependent variant (uniform select)
+                co = coff[(pw * QOPS + i) % V];
+                rb = rowb[(pw * QOPS + i) % V];
+            } else {
+                co = coff[i % V];
+                rb = rowb[i % V];
+            }
             if constexpr (BUF) {
-                const unsigned off = co == 0xFFFFFFF0u ? co : __umul24((unsigned)idx[i], row_bytes) + co;
+                const unsigned off = __umul24((unsigned)idx[i], rb) + co;
                 dma16_buf<RGCN_NT_H>(rsrc, off, dst);
             } else {
                 const float* gp = (idx[i] < n_rows && co != 0xFFFFFFF0u)
@@ -149,17 +158,16 @@ struct RowGather {
 
     __device__ __forceinline__ void issue(const float* __restrict__ base, unsigned bytes, int n_rows, int ld,
                                           int idxv, float* slot_base) const {
-        // all cross-lane index fetches first (one LDS-crossbar round trip for the batch, not one per DMA)
+        // all cross-lane index fetches first (one LDS-crossbar round trip for the batch, not one per DMA);
+        // constant address + immediate offset per fetch: no address arithmetic in the loop
         int idx[NOPS];
 #pragma unroll
-        for (int i = 0; i < NOPS; ++i) idx[i] = __shfl(idxv, i * RPI + rsub);
+        for (int i = 0; i < NOPS; ++i) idx[i] = __builtin_amdgcn_ds_bpermute(perm_addr + i * RPI * 4, idxv);
         if constexpr (BUF) {
             const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
-            const unsigned row_bytes = (unsigned)ld * 4u;
 #pragma unroll
             for (int i = 0; i < NOPS; ++i) {
-                const unsigned co = coff[i % V];
-                const unsigned off = co == 0xFFFFFFF0u ? co : __umul24((unsigned)idx[i], row_bytes) + co;
+                const unsigned off = __umul24((unsigned)idx[i], rowb[i % V]) + coff[i % V];
                 dma16_buf(rsrc, off, slot_base + i * RPI * W);
             }
         } else {
@@ -566,7 +574,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         const int pw = wave;
         int knext = pw;                                   // this wave's next chunk
         RowGather<KP, kRowRead, BUF> gather;
-        gather.init(lane, (a.dbg & 2) ? 0 : a.din4);
+        gather.init(lane, (a.dbg & 2) ? 0 : a.din4, a.ldx);
         // Row indices of this wave's NEXT chunk: one coalesced load, issued right after the current
         // chunk's DMAs and not touched until the wave's next turn 4 iterations later (any use here would
         // make hipcc wait vmcnt(0) on the spot, i.e. for the DMAs just issued).  The address is clamped
@@ -831,8 +839,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         int idx_h = 0, idx_g = 0;
         RowGather<KP, kColRead, BUF> gather_h;
         RowGather<NP, kColRead, BUF> gather_g;
-        gather_h.init(lane, a.din4);
-        gather_g.init(lane, a.dout4);
+        gather_h.init(lane, a.din4, a.ldx);
+        gather_g.init(lane, a.dout4, a.ldg);
         // raw index loads for the wave's next chunk; combined into row ids only at its next turn
         auto load_idx = [&](int k) {
             const int kk = k < nch ? k : nch - 1;
@@ -1070,8 +1078,8 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
         int* idxg = idxh + IR * kChunk;                         // [IR][64] slot_dstl
         RowGather<KP, kLinear, BUF> gather_h;
         RowGather<NP, kLinear, BUF> gather_g;
-        gather_h.init(lane, a.din4);
-        gather_g.init(lane, a.dout4);
+        gather_h.init(lane, a.din4, a.ldx);
+        gather_g.init(lane, a.dout4, a.ldg);
         constexpr int OPS_ROWS = KP / 16 + NP / 16;             // row DMAs of one wave per chunk
         auto chunk_of = [&](int k) { return ldc(a.rel_order, i0 + (k < nch ? k : nch - 1)); };
         // chunk ids for the NEXT step are fetched (scalar loads) during the current one
