@@ -225,8 +225,14 @@ struct TileArgs {
 template <int NP>
 constexpr int kAccStride = NP + 4;
 
+// second launch bound = waves per SIMD the register allocation must allow.  2: one 8-wave workgroup per CU at
+// full register budget; two workgroups per CU (bound 4 = 128 VGPRs, tiles of 160 nodes, RGCN_LDS_KB=80) measured
+// no faster (11.5 vs 11.6 ms): the limiter is SIMD issue, not latency
+#ifndef RGCN_TILE_WAVES
+#define RGCN_TILE_WAVES 2
+#endif
 template <int KP, int NP, int NBUF, bool BUF>
-__global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a) {
+__global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(const TileArgs a) {
     constexpr int KT = KP / 16, NT = NP / 16;
     constexpr int D = NBUF - 1;                  // chunks the producers run ahead
     static_assert(D >= 1 && D <= kProducerWaves, "one chunk in flight per producer wave");
@@ -293,6 +299,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bwait = 0, st_bar = 0;
+        unsigned long long st_nrt[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0};
 #endif
         for (int it = 0; it < nch; ++it) {
             STAMP(t0);
@@ -502,8 +509,12 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
                         // consecutive tiles may hit the same accumulator row.
                         if (step > NRT) continue;
                         if (step + 1 < NRT) load_ops(ops[step + 1], step + 1, tr_c);
-                        if (step >= 1) stage_c_t(ops[step - 1], tl[step - 1]);
-                        if (step < NRT) stage_b_t(ops[step], tl[step]);
+                        if (RGCN_ABL & 2) {
+                            if (step >= 1) asm volatile("" ::"v"(tl[step - 1].y[0]), "v"(tl[step - 1].z[0]), "v"(ops[step - 1].w1), "v"(ops[step - 1].d1));
+                        } else {
+                            if (step >= 1) stage_c_t(ops[step - 1], tl[step - 1]);
+                            if (step < NRT) stage_b_t(ops[step], tl[step]);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         if (step < NRT) stage_a_t(ops[step], tl[step]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -555,11 +566,18 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
             STAMP_ADD(st_comp, t1, t2);
             STAMP_ADD(st_bwait, t2, t3);
             STAMP_ADD(st_bar, t3, t4);
+#ifdef RGCN_STAMPS
+            if (nrt >= 1 && nrt <= 4) {
+                st_nrt[nrt - 1] += t2 - t1;
+                st_cnt[nrt - 1] += 1;
+            }
+#endif
         }
 #ifdef RGCN_STAMPS
         if (g_stamps && cwv == 0 && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
             o[0] = st_scal; o[1] = st_comp; o[2] = st_bwait; o[3] = st_bar;
+            for (int i = 0; i < 4; ++i) { o[8 + i] = st_nrt[i]; o[12 + i] = st_cnt[i]; }
         }
 #endif
         // tell the waitcnt pass that no consumer load is pending when the producer code (next in program
@@ -619,7 +637,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_tile_kernel(const TileArgs a
         wait_vmcnt<0>();
 #ifdef RGCN_STAMPS
         if (g_stamps && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
             if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
             if (pw == 1) o[7] = nch;
         }
@@ -822,7 +840,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         }
 #ifdef RGCN_STAMPS
         if (g_stamps && cwv == 0 && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
             o[0] = st_scal; o[1] = st_comp; o[2] = 0; o[3] = st_bar;
         }
 #endif
@@ -881,7 +899,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         wait_vmcnt<0>();
 #ifdef RGCN_STAMPS
         if (g_stamps && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
             if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
             if (pw == 1) o[7] = nch;
         }
@@ -1053,7 +1071,7 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
         }
 #ifdef RGCN_STAMPS
         if (g_stamps && cwv == 0 && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
             o[0] = st_scal; o[1] = st_comp; o[2] = 0; o[3] = st_bar;
         }
 #endif
@@ -1136,7 +1154,7 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
         wait_vmcnt<0>();
 #ifdef RGCN_STAMPS
         if (g_stamps && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
             if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
             if (pw == 1) o[7] = nch;
         }
@@ -1247,8 +1265,10 @@ static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
     auto bytes = [&](int nbuf) {
         return sizeof(float) * ((size_t)(a.tile + 1) * kAccStride<NP> + (size_t)nbuf * kChunk * (KP + 2));
     };
-    if (KP < 128 && bytes(4) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 4>(a, n_tiles, bytes(4), stream);
-    if (KP < 128 && bytes(3) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 3>(a, n_tiles, bytes(3), stream);
+    const char* cap_s = getenv("RGCN_LDS_KB");     // experiment knob: LDS budget per workgroup
+    const size_t cap = cap_s ? (size_t)atoi(cap_s) * 1024 : (size_t)kLdsBytes;
+    if (KP < 128 && bytes(4) <= cap) return launch_tile_nbuf<KP, NP, 4>(a, n_tiles, bytes(4), stream);
+    if (KP < 128 && bytes(3) <= cap) return launch_tile_nbuf<KP, NP, 3>(a, n_tiles, bytes(3), stream);
     if (bytes(2) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 2>(a, n_tiles, bytes(2), stream);
     return RGCN_ERR_LDS;
 }

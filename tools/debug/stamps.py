@@ -21,7 +21,7 @@ tile = int(os.environ.get("RGCN_TILE", P.choose_tile(n, e, 32, 64, 64)))
 plans = P.build_graph_plans(ei, et, n, 32, tile)
 print("tile", tile)
 fp = plans.fwd
-stamps = torch.zeros(fp.n_tiles * 8, dtype=torch.int64, device=dev)
+stamps = torch.zeros(max(fp.n_tiles, 1024) * 16, dtype=torch.int64, device=dev)
 lib.rgcn_debug_set_stamps.argtypes = [ctypes.c_void_p]
 assert lib.rgcn_debug_set_stamps(stamps.data_ptr()) == 0
 out = torch.empty(n, 64, device=dev)
@@ -36,7 +36,9 @@ else:
         _lib.bwd_dw(_lib.plan_struct(fp), x, 64, dg, 64, dwt, drt, dbt)
 torch.cuda.synchronize()
 print("kernel:", which)
-s = stamps.cpu().numpy().reshape(-1, 8).astype(np.float64)
+s = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64)
+if which == 'fwd':
+    s = s[:fp.n_tiles]
 nch = s[:, 7]
 tot_c = s[:, 0:4].sum(1); tot_p = s[:, 4:7].sum(1)
 print("SGB", os.environ.get("RGCN_SGB", "0"), "ABL", abl, "tiles", len(s), "chunks/tile mean", nch.mean())
@@ -44,3 +46,7 @@ names = ["cons scalar-loads", "cons compute", "cons B-wait", "cons barrier", "pr
 for i, nm in enumerate(names):
     print(f"{nm:20s} {s[:, i].sum() / nch.sum():9.1f} cycles/chunk")
 print(f"consumer loop total {tot_c.sum() / nch.sum():9.1f} cycles/chunk; producer wave0 loop total {tot_p.sum() / nch.sum():9.1f}")
+if which == "fwd":
+    for i in range(4):
+        c = s[:, 12 + i].sum()
+        print(f"chunks with {i + 1} row tiles: {int(c):9d}  compute {s[:, 8 + i].sum() / max(c, 1):8.1f} cycles/chunk")
