@@ -359,17 +359,18 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
             };
             auto load_ops = [&](Ops& o, int rt, auto tr_c) {
                 const int row = rt * 16 + rowl;
-#pragma unroll
-                for (int j = 0; j < KT; ++j) {
-                    const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
-                    o.av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
-                }
+                // weight / metadata first: the accumulator address of the tile is the first thing computed from it
                 if constexpr (decltype(tr_c)::value) {
                     o.w1 = wb[rt * 16 + rowl];
                     o.d1 = db[rt * 16 + rowl];
                 } else {
                     o.w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
                     o.d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
+                }
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
+                    o.av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
                 }
             };
             // accumulator row (low 24 bits of the plan's metadata word) -> LDS address of this lane's column(s):
@@ -508,7 +509,6 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
                         // the MFMA->VALU->MFMA switch is paid once.  Store(t-1) precedes read(t) in program order:
                         // consecutive tiles may hit the same accumulator row.
                         if (step > NRT) continue;
-                        if (step + 1 < NRT) load_ops(ops[step + 1], step + 1, tr_c);
                         if (RGCN_ABL & 2) {
                             if (step >= 1) asm volatile("" ::"v"(tl[step - 1].y[0]), "v"(tl[step - 1].z[0]), "v"(ops[step - 1].w1), "v"(ops[step - 1].d1));
                         } else {
@@ -516,7 +516,17 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
                             if (step < NRT) stage_b_t(ops[step], tl[step]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        // the next tile's operand reads go INSIDE this tile's MFMA block (an LDS instruction between
+                        // two MFMAs costs ~2 cycles; in front of the block it costs its full issue slot)
+                        if (step + 1 < NRT) load_ops(ops[step + 1], step + 1, tr_c);
                         if (step < NRT) stage_a_t(ops[step], tl[step]);
+                        if (step + 1 < NRT) {
+#pragma unroll
+                            for (int i = 0; i < KT + 1; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         continue;
                     }
