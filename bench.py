@@ -18,7 +18,8 @@ edge-partitioned by destination range (strong scaling); every step includes the 
 all-gathers and the weight-gradient all-reduce.  value = E * K / max-over-ranks time.
 
 The JSON line also carries `roofline` for the dominant kernel (HIP-event timed per launch; algorithmic
-bytes of SURVEY.md 8d / DESIGN.md) and `cpu_baseline`: the oracle's PyG-loop restatement timed on this
+bytes and flops of SURVEY.md 8d / DESIGN.md; the binding roof is the one that needs more time at its peak -- at
+64 -> 64 in exact fp32 that is the fp32 MFMA peak, with the HBM figures beside it) and `cpu_baseline`: the oracle's PyG-loop restatement timed on this
 host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -36,6 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PMC_TRAFFIC_FILE = "r01c_pmc_traffic.json"   # newest committed PMC pass
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), 155 measured
 
 
 def algorithmic_bytes(e, n, r, din, dout):
@@ -45,6 +48,15 @@ def algorithmic_bytes(e, n, r, din, dout):
     dx = e * (8 + 4 * dout) + n * (4 + 4 * dout + 4 * din) + w
     dw = e * (8 + 4 * din) + n * (4 + 4 * din) + w          # dOut counted once, in dx
     return {"fwd": fwd, "dx": dx, "dw": dw}
+
+
+def algorithmic_flops(e, n, r, din, dout):
+    """SURVEY.md 8d, per launch: one in x out contraction per distinct (dst, relation) pair S (uniform graph:
+    S = N R' (1 - exp(-E / (N R')))) and per node (root), plus the E x in adds of the aggregation.  The kernels
+    execute 2 in out (E + N) -- they contract per edge -- so the achieved figure is the conservative one."""
+    s_pairs = n * r * (1.0 - math.exp(-e / (n * r)))
+    fwd = 2.0 * din * dout * (s_pairs + n) + e * din
+    return {"fwd": fwd, "dx": 2.0 * din * dout * (s_pairs + n) + e * dout, "dw": fwd}
 
 
 def synthetic_on_device(n, e, r, din, dout, dev, seed=0):
@@ -228,17 +240,33 @@ def main():
         kname, kbytes, kms = "rgcn_tile_kernel<64,64,3> (fwd + dX launches)", (alg["fwd"] + alg["dx"]) / 2, tile_ms / 2
     else:
         kname, kbytes, kms = "rgcn_dw_wide_kernel<64,64,4>", alg["dw"], kernel_ms["dw"]
-    achieved = kbytes / (kms * 1e-3) / 1e9
+    hbm_achieved = kbytes / (kms * 1e-3) / 1e9
+    flops = algorithmic_flops(e / world, n / world, r, d, d)
+    kflops = (flops["fwd"] + flops["dx"]) / 2 if "tile" in kname else flops["dw"]
+    mfma_achieved = kflops / (kms * 1e-3) / 1e12
+    # Which roof binds: the kernels contract in exact fp32 on the matrix cores (tolerance 1e-5 rules out bf16), whose
+    # dense peak is 1/16 of bf16's -- at 64 -> 64 the contraction needs more time at its peak than the gather at HBM's
+    t_hbm, t_mfma = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_F32_PEAK_TFLOPS * 1e12)
     # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs,
     # gfx950 correction applied) committed under profiles/ -- only quoted for the workload they were taken on
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
         if world == 1 and (n, e, r, d) == (10_000_000, 100_000_000, 32, 64):
             key = "rgcn::rgcn_tile_kernel<64, 64, 3, true>" if "tile" in kname else "rgcn::rgcn_dw_wide_kernel<64, 64, 4, true, 4>"
             traffic = pm["kernels"][key]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
+    if t_mfma >= t_hbm:
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": mfma_achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                    "algorithmic_flops_per_launch": kflops}
+    else:
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": hbm_achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic}
+    roofline.update({"algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
+                     "hbm_achieved_GBs": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
+                     "t_at_peak_ms": {"hbm": t_hbm * 1e3, "mfma_f32": t_mfma * 1e3}})
 
     if rank == 0:
         rec = {
@@ -258,9 +286,7 @@ def main():
                                    f"full-graph layer fwd+bwd (BASELINE.json configs[3])",
                        "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
                        "partition": f"dst-range x{world}" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms},
+            "roofline": roofline,
             "kernel_ms": kernel_ms,
             "plan_build_s": plan_s,
             "plan_bytes": sum(p.nbytes() for p in fps + bps),
