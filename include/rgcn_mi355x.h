@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 6
+#define RGCN_ABI_VERSION 7
 #define RGCN_CHUNK 64 /* edge slots per chunk == rows of one LDS ring slot */
 #define RGCN_MAX_WIDTH 128
 
@@ -59,18 +59,21 @@ typedef struct rgcn_plan {
     int32_t tile;          /* output nodes per tile (multiple of 16) */
     int32_t n_tiles;
     int32_t n_chunks;
+    int32_t chunk;         /* edge slots per chunk: 64 or 128 (rows of one LDS ring slot of the forward / dX kernel) */
+    int32_t n_units;       /* entries of rel_order */
     const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
     const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */
-    const int32_t* chunk_cnt;  /* [n_chunks] slots of the chunk's used 16-slot MFMA row tiles (16, 32, 48 or 64);
+    const int32_t* chunk_cnt;  /* [n_chunks] slots of the chunk's used 16-slot MFMA row tiles (16, 32, ... chunk);
                                 * padding slots sit at the end of every row tile */
     const int32_t* chunk_tile; /* [n_chunks] */
     const int32_t* chunk_flags; /* [n_chunks] bit t: row tile t holds a repeated destination (needs the run-sum) */
-    const int32_t* rel_order;  /* [n_chunks] chunk ids sorted by (relation, tile) */
-    const int32_t* slot_src;   /* [n_chunks * 64] row to gather; padding = n_nodes (one past the last row) */
-    const float* slot_w;       /* [n_chunks * 64] edge weight 1/max(1,c[dst,rel]), 0 = padding */
-    const int32_t* slot_row;   /* [n_chunks * 64] row of the owned range the slot scatters into (tile * tile_size + row
+    const int32_t* rel_order;  /* [n_units] the weight-gradient walk: non-empty 64-slot units (unit u = slots
+                                * [64 u, 64 u + 64), chunk u / (chunk / 64)) sorted by (relation, tile) */
+    const int32_t* slot_src;   /* [n_chunks * chunk] row to gather; padding = n_nodes (one past the last row) */
+    const float* slot_w;       /* [n_chunks * chunk] edge weight 1/max(1,c[dst,rel]), 0 = padding */
+    const int32_t* slot_row;   /* [n_chunks * chunk] row of the owned range the slot scatters into (tile * tile_size + row
                                 * in tile), ascending inside a 16-slot row tile; padding = n_owned */
-    const int32_t* slot_acc;   /* [n_chunks * 64] forward run-sum metadata per slot: (position 0..15 in the 16-slot
+    const int32_t* slot_acc;   /* [n_chunks * chunk] forward run-sum metadata per slot: (position 0..15 in the 16-slot
                                 * MFMA row tile of the slot ending this slot's run of equal destinations) << 24 |
                                 * (accumulator row written); the row is the slot's row in the tile if the slot
                                 * ends its run, else `tile` (dummy row) */

@@ -35,16 +35,25 @@ def _rows16(t: Tensor, width: int) -> Tensor:
     return t.contiguous()
 
 
-def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0, num_relations: int = 1) -> int:
-    """Output nodes per tile (plan.choose_tile): bounded by the LDS budget of the wider side, tuned to the
-    graph's density so that (tile, relation) groups fill their 64-slot chunks.  ``RGCN_TILE`` overrides."""
+def layout_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0,
+               num_relations: int = 1) -> Tuple[int, int]:
+    """(output nodes per tile, edge slots per chunk) for a layer (plan.choose_layout): bounded by the LDS budget of
+    the wider side, tuned to the graph's density.  ``RGCN_TILE`` / ``RGCN_CHUNK`` override (experiments)."""
     if not (1 <= in_channels <= 128 and 1 <= out_channels <= 128):
         raise ValueError(f"RGCNConv widths must be in 1..128, got {in_channels}->{out_channels}")
     import os
+    from .plan import choose_layout
+    tile, chunk = choose_layout(n_nodes, n_edges, num_relations, in_channels, out_channels)
     if "RGCN_TILE" in os.environ:
-        return int(os.environ["RGCN_TILE"])
-    from .plan import choose_tile
-    return choose_tile(n_nodes, n_edges, num_relations, in_channels, out_channels)
+        tile = int(os.environ["RGCN_TILE"])
+    if "RGCN_CHUNK" in os.environ:
+        chunk = int(os.environ["RGCN_CHUNK"])
+    return tile, chunk
+
+
+def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0, num_relations: int = 1) -> int:
+    """Output nodes per tile of ``layout_for``."""
+    return layout_for(in_channels, out_channels, n_nodes, n_edges, num_relations)[0]
 
 
 class DistContext:
@@ -271,11 +280,11 @@ class RGCNConv(nn.Module):
 
     def _plans(self, x: Tensor, edge_index: Tensor, edge_type: Tensor) -> GraphPlans:
         n = x.shape[0]
-        tile = tile_for(self.in_channels, self.out_channels, n, int(edge_type.shape[0]), self.num_relations)
+        tile, chunk = layout_for(self.in_channels, self.out_channels, n, int(edge_type.shape[0]), self.num_relations)
         if self.dist is None:
-            return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr)
+            return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk)
         from .dist import cached_rank_plans
-        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist)
+        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None) -> Tensor:
         assert edge_type is not None, "edge_type is required (PyG RGCNConv asserts the same)"

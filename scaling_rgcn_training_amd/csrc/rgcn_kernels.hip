@@ -231,11 +231,21 @@ constexpr int kAccStride = NP + 4;
 #ifndef RGCN_TILE_WAVES
 #define RGCN_TILE_WAVES 2
 #endif
-template <int KP, int NP, int NBUF, bool BUF>
-__global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(const TileArgs a) {
+// Producer waves of the tile kernel (experiment knob): 4 = one 8-wave workgroup per CU; 2 = 6-wave workgroups, two per
+// CU when their LDS fits twice (3 waves per SIMD at the full register budget)
+#ifndef RGCN_TILE_PW
+#define RGCN_TILE_PW 4
+#endif
+constexpr int kTileProducers = RGCN_TILE_PW;
+constexpr int kTileThreads = 64 * (kTileProducers + 4);
+
+// CH = edge slots per chunk = rows of one ring slot (64 or 128): a 128-slot chunk is consumed as two 64-row parts
+// with no barrier, metadata fetch or B swap between them
+template <int KP, int NP, int NBUF, bool BUF, int CH>
+__global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(const TileArgs a) {
     constexpr int KT = KP / 16, NT = NP / 16;
     constexpr int D = NBUF - 1;                  // chunks the producers run ahead
-    static_assert(D >= 1 && D <= kProducerWaves, "one chunk in flight per producer wave");
+    static_assert(D >= 1 && D <= kTileProducers, "one chunk in flight per producer wave");
     constexpr int CW = NT < 4 ? NT : 4;          // consumer waves that own output column slices
     constexpr int SL = NT < 4 ? 1 : NT / 4;      // column slices per consumer wave
     constexpr int LPR = KP / 4;
@@ -244,9 +254,9 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* out_lds = lds;                         // [tile + 1][LDO]  (row `tile`: dummy)
-    float* ring = lds + (a.tile + 1) * LDO;       // [NBUF][64][KP]
-    float* wring = ring + NBUF * kChunk * KP;     // [NBUF][64]
-    int* dring = (int*)(wring + NBUF * kChunk);   // [NBUF][64]
+    float* ring = lds + (a.tile + 1) * LDO;       // [NBUF][CH][KP]
+    float* wring = ring + NBUF * CH * KP;         // [NBUF][CH]
+    int* dring = (int*)(wring + NBUF * CH);       // [NBUF][CH]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -255,7 +265,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
     const int c0 = ldc(a.tile_ptr, tile);
     const int nch = ldc(a.tile_ptr, tile + 1) - c0;
 
-    for (int i = tid; i < (a.tile + 1) * LDO; i += kThreads) {
+    for (int i = tid; i < (a.tile + 1) * LDO; i += kTileThreads) {
         const int col = i % LDO;
         out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
     }
@@ -266,7 +276,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
     // with no LDS-DMA ahead of it the consumer code gets exact counted waits for its own B-fragment
     // loads; in a shared loop body every ring read was preceded by s_waitcnt vmcnt(0) ("a DMA may be
     // pending"), which un-overlapped the B prefetch from the MFMAs.
-    if (wave >= kProducerWaves) {
+    if (wave >= kTileProducers) {
         // ---- consumers: ring -> MFMA -> tile accumulator in LDS -----------------------------------
         // Consumer wave cw owns output column slices {cw + CW*s}; with fewer than 4 slices (NP < 64) the
         // surplus consumer waves only keep the barrier count (same time per row: the MFMA work per row
@@ -274,7 +284,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
         // update a plain LDS read-modify-write: no LDS float atomics (ds_add_f32 retires ~1 lane per 3
         // cycles on gfx950, ~190 cycles per wave-instruction: tools/probes/lds_atomic_rate.hip; it
         // was 60 % of the first version's kernel time) and bit-reproducible sums.
-        const int cwv = wave - kProducerWaves;
+        const int cwv = wave - kTileProducers;
         const bool active = cwv < CW;
         const int cw = cwv;
         const int rowl = lane & 15, kq = lane >> 4;
@@ -299,7 +309,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bwait = 0, st_bar = 0;
-        unsigned long long st_nrt[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0};
+        unsigned long long st_nrt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         for (int it = 0; it < nch; ++it) {
             STAMP(t0);
@@ -307,7 +317,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
             const int buf = it % NBUF;
             // chunk metadata arrives one iteration ahead (scalar loads issued a whole chunk earlier)
             const int cnt = cnt_pre;
-            const int flags = flags_pre;
+            const int flags_chunk = flags_pre;
             const int rel_next = rel_pre;
             if (it + 1 < nch) {
                 cnt_pre = ldc(a.chunk_cnt, chunk + 1);
@@ -334,10 +344,19 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
                     }
                 }
             }
-            const float* hb = ring + buf * kChunk * KP;
-            const float* wb = wring + buf * kChunk;
-            const int* db = dring + buf * kChunk;
-            const int nrt = (!active || (a.dbg & 1)) ? 0 : (cnt + 15) >> 4;
+            const int nrt_all = (!active || (a.dbg & 1)) ? 0 : (cnt + 15) >> 4;
+            const int flags_all = flags_chunk;
+            // A chunk without repeated destinations runs as ONE straight-line block over all its row tiles (up to
+            // CH / 16); otherwise 64-row parts of up to four tiles, each on the path its own flags ask for.
+            const bool whole = flags_all == 0;
+#pragma unroll
+            for (int part = 0; part < CH / 64; ++part) {
+            if (whole && part > 0) break;
+            const float* hb = ring + (buf * CH + 64 * part) * KP;
+            const float* wb = wring + buf * CH + 64 * part;
+            const int* db = dring + buf * CH + 64 * part;
+            const int nrt = whole ? nrt_all : (nrt_all - 4 * part < 4 ? nrt_all - 4 * part : 4);
+            const int flags = (flags_all >> (4 * part)) & 15;
             // Operands of one 16-row tile.  Rows of a chunk are sorted by destination, so equal
             // destinations are adjacent runs; a run ends at a change of destination or at the end of the row
             // tile (the next tile is processed after it).  Which slot ends each run, and which accumulator
@@ -387,20 +406,23 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
             // 4+ issue cycles ON TOP of the MFMA time, plus ~10 cycles per MFMA->VALU->MFMA switch
             // (tools/probes/mfma_f32_overlap.hip: only LDS traffic hides under v_mfma_f32_16x16x4_f32); the Y
             // layout spends 4 b32 reads + 4 b32 writes + 4 addresses + 6 more VALU per slice.
-            auto stage_a_t = [&](const Ops& o, Tile& t) {
+            // `half` 0 / 1: the first / second 2 KT MFMAs of each chain pair (the accumulate of the PREVIOUS tile is
+            // issued between the halves, see consume)
+            auto stage_a_t = [&](const Ops& o, Tile& t, int half) {
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
-                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 acc0 = t.y[s], acc1 = t.z[s];
+                    if (half == 0) acc0 = acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < KT; ++j) {
+                    for (int m = 0; m < 4 * KT; m += 2) {
+                        if ((m < 2 * KT) != (half == 0)) continue;
+                        const int j = m >> 2, i = m & 3;
                         if (RGCN_ABL & 1) {
                             acc0 += o.av[j];
                             continue;
                         }
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][0], o.av[j][0], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][1], o.av[j][1], acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][2], o.av[j][2], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][3], o.av[j][3], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][i], o.av[j][i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][i + 1], o.av[j][i + 1], acc1, 0, 0, 0);
                     }
                     t.y[s] = acc0;      // the two chains are folded in stage C's FMAs
                     t.z[s] = acc1;
@@ -509,6 +531,22 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
                         // the MFMA->VALU->MFMA switch is paid once.  Store(t-1) precedes read(t) in program order:
                         // consecutive tiles may hit the same accumulator row.
                         if (step > NRT) continue;
+                        // first half of this tile's MFMAs, the next tile's operand reads in between (an LDS
+                        // instruction between two MFMAs costs ~2 cycles; in front of the block its full issue slot)
+                        if (step + 1 < NRT) load_ops(ops[step + 1], step + 1, tr_c);
+                        if (step < NRT) stage_a_t(ops[step], tl[step], 0);
+                        if (step + 1 < NRT) {
+#pragma unroll
+                            for (int i = 0; i < KT; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // ONE group of vector instructions per tile, in the MIDDLE of its MFMA block: the store of
+                        // tile t-1 (its MFMA results completed during the first half: no pipeline drain) and the
+                        // address + accumulator read of tile t (used a whole block later).  Store(t-1) precedes
+                        // read(t) in program order: consecutive tiles may hit the same accumulator row.
                         if (RGCN_ABL & 2) {
                             if (step >= 1) asm volatile("" ::"v"(tl[step - 1].y[0]), "v"(tl[step - 1].z[0]), "v"(ops[step - 1].w1), "v"(ops[step - 1].d1));
                         } else {
@@ -516,17 +554,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
                             if (step < NRT) stage_b_t(ops[step], tl[step]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        // the next tile's operand reads go INSIDE this tile's MFMA block (an LDS instruction between
-                        // two MFMAs costs ~2 cycles; in front of the block it costs its full issue slot)
-                        if (step + 1 < NRT) load_ops(ops[step + 1], step + 1, tr_c);
-                        if (step < NRT) stage_a_t(ops[step], tl[step]);
-                        if (step + 1 < NRT) {
-#pragma unroll
-                            for (int i = 0; i < KT + 1; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                            }
-                        }
+                        if (step < NRT) stage_a_t(ops[step], tl[step], 1);
                         __builtin_amdgcn_sched_barrier(0);
                         continue;
                     }
@@ -546,6 +574,10 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
                     case 2: consume(integral_constant<int, 2>{}, std::true_type{}); break;
                     case 3: consume(integral_constant<int, 3>{}, std::true_type{}); break;
                     case 4: consume(integral_constant<int, 4>{}, std::true_type{}); break;
+                    case 5: if constexpr (CH > 64) consume(integral_constant<int, 5>{}, std::true_type{}); break;
+                    case 6: if constexpr (CH > 64) consume(integral_constant<int, 6>{}, std::true_type{}); break;
+                    case 7: if constexpr (CH > 64) consume(integral_constant<int, 7>{}, std::true_type{}); break;
+                    case 8: if constexpr (CH > 64) consume(integral_constant<int, 8>{}, std::true_type{}); break;
                     default: break;
                 }
             } else {
@@ -557,6 +589,8 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
                     default: break;
                 }
             }
+            }   // part
+            const int nrt = nrt_all;
             STAMP(t2);
             if (swap_b) {
                 if constexpr (kAsmPrefetch) wait_vmcnt<0>();   // the asm prefetch (this wave's only vector-memory traffic)
@@ -577,24 +611,26 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
             STAMP_ADD(st_bwait, t2, t3);
             STAMP_ADD(st_bar, t3, t4);
 #ifdef RGCN_STAMPS
-            if (nrt >= 1 && nrt <= 4) {
-                st_nrt[nrt - 1] += t2 - t1;
-                st_cnt[nrt - 1] += 1;
-            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (nrt == i + 1) {
+                    st_nrt[i] += t2 - t1;
+                    st_cnt[i] += 1;
+                }
 #endif
         }
 #ifdef RGCN_STAMPS
         if (g_stamps && cwv == 0 && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
             o[0] = st_scal; o[1] = st_comp; o[2] = st_bwait; o[3] = st_bar;
-            for (int i = 0; i < 4; ++i) { o[8 + i] = st_nrt[i]; o[12 + i] = st_cnt[i]; }
+            for (int i = 0; i < 8; ++i) { o[8 + i] = st_nrt[i]; o[16 + i] = st_cnt[i]; }
         }
 #endif
         // tell the waitcnt pass that no consumer load is pending when the producer code (next in program
         // order) reuses these registers; otherwise it waits vmcnt(0) between the prologue DMAs
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
-    if (wave < kProducerWaves) {
+    if (wave < kTileProducers) {
         // The producers' few instructions must not queue behind the consumer wave's MFMAs on the shared SIMD
         // (issue is arbitrated by priority, then age; an fp32 MFMA holds the pipe 32 cycles): RGCN_PRIO
         __builtin_amdgcn_s_setprio(RGCN_PRIO);
@@ -607,22 +643,29 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
         // chunk's DMAs and not touched until the wave's next turn 4 iterations later (any use here would
         // make hipcc wait vmcnt(0) on the spot, i.e. for the DMAs just issued).  The address is clamped
         // so the load is always valid; issue() only runs for k < nch.
-        auto load_idx = [&](int k) {
+        constexpr int HALVES = CH / 64;
+        auto load_idx = [&](int k, int h) {
             const int kk = k < nch ? k : nch - 1;
-            return a.slot_src[(size_t)(c0 + kk) * kChunk + lane];
+            return a.slot_src[(size_t)(c0 + kk) * CH + 64 * h + lane];
         };
-        int idxv = load_idx(knext);
+        int idxv[HALVES];
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) idxv[h] = load_idx(knext, h);
         auto issue = [&](int k) {                         // k == knext
             const int chunk = c0 + k, buf = k % NBUF;
-            gather.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idxv, ring + buf * kChunk * KP);
-            dma4(a.slot_w + (size_t)chunk * kChunk + lane, wring + buf * kChunk);
-            dma4(a.slot_acc + (size_t)chunk * kChunk + lane, dring + buf * kChunk);
-            knext += kProducerWaves;
-            idxv = load_idx(knext);                       // youngest op of this wave from here on
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                gather.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idxv[h], ring + (buf * CH + 64 * h) * KP);
+                dma4(a.slot_w + (size_t)chunk * CH + 64 * h + lane, wring + buf * CH + 64 * h);
+                dma4(a.slot_acc + (size_t)chunk * CH + 64 * h + lane, dring + buf * CH + 64 * h);
+            }
+            knext += kTileProducers;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) idxv[h] = load_idx(knext, h);   // youngest ops of this wave from here on
         };
 #pragma unroll
         for (int k = 0; k < D; ++k)
-            if (k % kProducerWaves == pw && k < nch) issue(k);
+            if (k % kTileProducers == pw && k < nch) issue(k);
         if (pw == 0) wait_vmcnt<0>();                     // chunk 0 landed
         wg_barrier();                                     // chunk 0 (and the accumulator init) visible
 #ifdef RGCN_STAMPS
@@ -632,11 +675,11 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
             // slot (it+D)%NBUF held chunk it-1, which the consumers finished before the last barrier
             const int ki = it + D, kw = it + 1;
             STAMP(p0);
-            if (ki % kProducerWaves == pw && ki < nch) issue(ki);
+            if (ki % kTileProducers == pw && ki < nch) issue(ki);
             STAMP(p1);
             // a wave has at most ONE chunk in flight (D <= 4), plus the index load issued with it (which
             // hipcc may schedule among the DMAs): vmcnt(0) is exact
-            if (kw % kProducerWaves == pw && kw < nch) wait_vmcnt<0>();   // chunk it+1 landed
+            if (kw % kTileProducers == pw && kw < nch) wait_vmcnt<0>();   // chunk it+1 landed
             STAMP(p2);
             wg_barrier();
             STAMP(p3);
@@ -647,7 +690,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
         wait_vmcnt<0>();
 #ifdef RGCN_STAMPS
         if (g_stamps && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
             if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
             if (pw == 1) o[7] = nch;
         }
@@ -658,7 +701,7 @@ __global__ void __launch_bounds__(kThreads, RGCN_TILE_WAVES) rgcn_tile_kernel(co
     const int row0 = tile * a.tile;
     const int rows = min(a.tile, a.n_owned - row0);
     const int o4 = (a.dout + 3) >> 2;
-    for (int i = tid; i < rows * o4; i += kThreads) {
+    for (int i = tid; i < rows * o4; i += kTileThreads) {
         const int r = i / o4, c4 = i - r * o4;
         const f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
         *(f32x4*)(a.out + (size_t)(row0 + r) * a.ldo + c4 * 4) = v;
@@ -685,7 +728,8 @@ struct DwArgs {
     int n_rows, n_owned;  // rows of x / of g (padding slots gather the row one past the end)
     float* slabs;      // [(nblocks + R' + 1) * 4][KP*NP]
     float* bias_slabs; // [nblocks * 4][NP]
-    int ldx, din4, ldg, dout4, tile, n_chunks, num_rel;
+    int ldx, din4, ldg, dout4, tile, n_units, num_rel;
+    int ushift;        // log2(units per chunk): unit u belongs to chunk u >> ushift, rows 64 * (u & mask) .. + 63 of it
 };
 
 template <int KP, int NP, int NBUF, bool BUF>
@@ -706,8 +750,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = gridDim.x, b = blockIdx.x;
-    const int i0 = (int)((long)b * a.n_chunks / nb);
-    const int i1 = (int)((long)(b + 1) * a.n_chunks / nb);
+    const int i0 = (int)((long)b * a.n_units / nb);
+    const int i1 = (int)((long)(b + 1) * a.n_units / nb);
     const int nch = i1 - i0;
     if (nch <= 0) return;
 
@@ -753,9 +797,14 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
     if (wave >= kProducerWaves) {
         zero_acc();
         // chunk metadata one iteration ahead (three dependent scalar loads per chunk otherwise)
+        // the walk is over 64-row UNITS (rel_order); a unit's metadata is its chunk's
+        auto unit_cnt = [&](int unit) {
+            const int c = ldc(a.chunk_cnt, unit >> a.ushift) - kChunk * (unit & ((1 << a.ushift) - 1));
+            return c < kChunk ? c : kChunk;
+        };
         int chunk_pre = ldc(a.rel_order, i0);
-        int cnt_pre = ldc(a.chunk_cnt, chunk_pre);
-        int relv_pre = ldc(a.chunk_rel, chunk_pre);
+        int cnt_pre = unit_cnt(chunk_pre);
+        int relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bar = 0;
@@ -767,8 +816,8 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
             const int rel = relv_pre;
             if (it + 1 < nch) {
                 chunk_pre = ldc(a.rel_order, i0 + it + 1);
-                cnt_pre = ldc(a.chunk_cnt, chunk_pre);
-                relv_pre = ldc(a.chunk_rel, chunk_pre);
+                cnt_pre = unit_cnt(chunk_pre);
+                relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
             }
             STAMP(t1);
             if (rel != rel_cur) {
@@ -850,7 +899,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         }
 #ifdef RGCN_STAMPS
         if (g_stamps && cwv == 0 && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
             o[0] = st_scal; o[1] = st_comp; o[2] = 0; o[3] = st_bar;
         }
 #endif
@@ -909,7 +958,7 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
         wait_vmcnt<0>();
 #ifdef RGCN_STAMPS
         if (g_stamps && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
             if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
             if (pw == 1) o[7] = nch;
         }
@@ -947,8 +996,8 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = gridDim.x, b = blockIdx.x;
-    const int i0 = (int)((long)b * a.n_chunks / nb);
-    const int i1 = (int)((long)(b + 1) * a.n_chunks / nb);
+    const int i0 = (int)((long)b * a.n_units / nb);
+    const int i1 = (int)((long)(b + 1) * a.n_units / nb);
     const int nch = i1 - i0;
     if (nch <= 0) return;
 
@@ -992,9 +1041,14 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
             }
         };
         zero_acc();
+        // the walk is over 64-row UNITS (rel_order); a unit's metadata is its chunk's
+        auto unit_cnt = [&](int unit) {
+            const int c = ldc(a.chunk_cnt, unit >> a.ushift) - kChunk * (unit & ((1 << a.ushift) - 1));
+            return c < kChunk ? c : kChunk;
+        };
         int chunk_pre = ldc(a.rel_order, i0);
-        int cnt_pre = ldc(a.chunk_cnt, chunk_pre);
-        int relv_pre = ldc(a.chunk_rel, chunk_pre);
+        int cnt_pre = unit_cnt(chunk_pre);
+        int relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
         wg_barrier();   // producers: index vectors landed
         wg_barrier();   // producers: chunk 0 landed
 #ifdef RGCN_STAMPS
@@ -1007,8 +1061,8 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
             const int rel = relv_pre;
             if (it + 1 < nch) {
                 chunk_pre = ldc(a.rel_order, i0 + it + 1);
-                cnt_pre = ldc(a.chunk_cnt, chunk_pre);
-                relv_pre = ldc(a.chunk_rel, chunk_pre);
+                cnt_pre = unit_cnt(chunk_pre);
+                relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
             }
             STAMP(t1);
             if (rel != rel_cur) {
@@ -1081,7 +1135,7 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
         }
 #ifdef RGCN_STAMPS
         if (g_stamps && cwv == 0 && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
             o[0] = st_scal; o[1] = st_comp; o[2] = 0; o[3] = st_bar;
         }
 #endif
@@ -1164,7 +1218,7 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
         wait_vmcnt<0>();
 #ifdef RGCN_STAMPS
         if (g_stamps && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 16;
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
             if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
             if (pw == 1) o[7] = nch;
         }
@@ -1177,7 +1231,7 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
 // The workgroups whose chunk range touches relation r are a contiguous run [b_lo, b_hi].
 __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
                                       const int* __restrict__ rel_order, const int* __restrict__ chunk_rel,
-                                      int n_chunks, int nblocks, int num_rel, int KP, int NP, int din, int dout,
+                                      int n_chunks, int ushift, int nblocks, int num_rel, int KP, int NP, int din, int dout,
                                       float* __restrict__ d_weight, float* __restrict__ d_root,
                                       float* __restrict__ d_bias) {
     const int r = blockIdx.x;
@@ -1199,7 +1253,7 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
             const int i0 = (int)((long)b * n_chunks / nblocks);
             const int i1 = (int)((long)(b + 1) * n_chunks / nblocks);
             if (i1 <= i0) continue;
-            const int first = chunk_rel[rel_order[i0]], last = chunk_rel[rel_order[i1 - 1]];
+            const int first = chunk_rel[rel_order[i0] >> ushift], last = chunk_rel[rel_order[i1 - 1] >> ushift];
             if (r >= first && r <= last) {
                 lo = b < lo ? b : lo;
                 hi = b;
@@ -1237,7 +1291,8 @@ static int check_plan(const rgcn_plan_t* p) {
         !p->slot_w || !p->slot_row || !p->slot_acc)
         return RGCN_ERR_NULL;
     if (p->n_nodes <= 0 || p->n_owned <= 0 || p->num_relations <= 0 || p->tile <= 0 || (p->tile % 16) != 0 || p->tile > 32768 ||
-        p->n_tiles <= 0 || p->n_chunks < p->n_tiles || (long)p->n_tiles * p->tile < p->n_owned)
+        p->n_tiles <= 0 || p->n_chunks < p->n_tiles || (long)p->n_tiles * p->tile < p->n_owned ||
+        (p->chunk != 64 && p->chunk != 128) || p->n_units < p->n_chunks || p->n_units > p->n_chunks * (p->chunk / 64))
         return RGCN_ERR_PLAN;
     return RGCN_OK;
 }
@@ -1260,46 +1315,53 @@ static int check_stride(int ld, int width) {
     return RGCN_OK;
 }
 
-template <int KP, int NP, int NBUF>
+template <int KP, int NP, int NBUF, int CH>
 static int launch_tile_nbuf(const TileArgs& a, int n_tiles, size_t lds, hipStream_t stream) {
-    auto kern = a.x_bytes ? rgcn_tile_kernel<KP, NP, NBUF, true> : rgcn_tile_kernel<KP, NP, NBUF, false>;
+    auto kern = a.x_bytes ? rgcn_tile_kernel<KP, NP, NBUF, true, CH> : rgcn_tile_kernel<KP, NP, NBUF, false, CH>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kTileThreads), lds, stream, a);
     return (int)hipGetLastError();
 }
-
 // deepest DMA ring (4, 3 or 2 slots) that fits beside the tile accumulator in the 160 KiB LDS
 template <int KP, int NP>
-static int launch_tile(const TileArgs& a, int n_tiles, hipStream_t stream) {
+static int launch_tile(const TileArgs& a, int n_tiles, int chunk, hipStream_t stream) {
     auto bytes = [&](int nbuf) {
-        return sizeof(float) * ((size_t)(a.tile + 1) * kAccStride<NP> + (size_t)nbuf * kChunk * (KP + 2));
+        return sizeof(float) * ((size_t)(a.tile + 1) * kAccStride<NP> + (size_t)nbuf * chunk * (KP + 2));
     };
     const char* cap_s = getenv("RGCN_LDS_KB");     // experiment knob: LDS budget per workgroup
     const size_t cap = cap_s ? (size_t)atoi(cap_s) * 1024 : (size_t)kLdsBytes;
-    if (KP < 128 && bytes(4) <= cap) return launch_tile_nbuf<KP, NP, 4>(a, n_tiles, bytes(4), stream);
-    if (KP < 128 && bytes(3) <= cap) return launch_tile_nbuf<KP, NP, 3>(a, n_tiles, bytes(3), stream);
-    if (bytes(2) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 2>(a, n_tiles, bytes(2), stream);
+    if (chunk == 128) {
+        // 128-slot chunks: built for the widths whose ring slots leave room for a useful tile (KP <= 64)
+        if constexpr (KP <= 64) {
+            if (bytes(3) <= cap) return launch_tile_nbuf<KP, NP, 3, 128>(a, n_tiles, bytes(3), stream);
+            if (bytes(2) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 2, 128>(a, n_tiles, bytes(2), stream);
+        }
+        return RGCN_ERR_LDS;
+    }
+    if constexpr (kTileProducers >= 3)
+        if (KP < 128 && bytes(4) <= cap) return launch_tile_nbuf<KP, NP, 4, 64>(a, n_tiles, bytes(4), stream);
+    if (KP < 128 && bytes(3) <= cap) return launch_tile_nbuf<KP, NP, 3, 64>(a, n_tiles, bytes(3), stream);
+    if (bytes(2) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 2, 64>(a, n_tiles, bytes(2), stream);
     return RGCN_ERR_LDS;
 }
-
 template <int KP>
-static int dispatch_tile_np(int NP, const TileArgs& a, int n_tiles, hipStream_t s) {
+static int dispatch_tile_np(int NP, const TileArgs& a, int n_tiles, int chunk, hipStream_t s) {
     switch (NP) {
-        case 16: return launch_tile<KP, 16>(a, n_tiles, s);
-        case 32: return launch_tile<KP, 32>(a, n_tiles, s);
-        case 64: return launch_tile<KP, 64>(a, n_tiles, s);
-        case 128: return launch_tile<KP, 128>(a, n_tiles, s);
+        case 16: return launch_tile<KP, 16>(a, n_tiles, chunk, s);
+        case 32: return launch_tile<KP, 32>(a, n_tiles, chunk, s);
+        case 64: return launch_tile<KP, 64>(a, n_tiles, chunk, s);
+        case 128: return launch_tile<KP, 128>(a, n_tiles, chunk, s);
     }
     return RGCN_ERR_WIDTH;
 }
 
-static int dispatch_tile(int KP, int NP, const TileArgs& a, int n_tiles, hipStream_t s) {
+static int dispatch_tile(int KP, int NP, const TileArgs& a, int n_tiles, int chunk, hipStream_t s) {
     switch (KP) {
-        case 16: return dispatch_tile_np<16>(NP, a, n_tiles, s);
-        case 32: return dispatch_tile_np<32>(NP, a, n_tiles, s);
-        case 64: return dispatch_tile_np<64>(NP, a, n_tiles, s);
-        case 128: return dispatch_tile_np<128>(NP, a, n_tiles, s);
+        case 16: return dispatch_tile_np<16>(NP, a, n_tiles, chunk, s);
+        case 32: return dispatch_tile_np<32>(NP, a, n_tiles, chunk, s);
+        case 64: return dispatch_tile_np<64>(NP, a, n_tiles, chunk, s);
+        case 128: return dispatch_tile_np<128>(NP, a, n_tiles, chunk, s);
     }
     return RGCN_ERR_WIDTH;
 }
@@ -1334,7 +1396,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.n_owned = plan->n_owned;
     const char* dbg = getenv("RGCN_DEBUG_MODE");
     a.dbg = dbg ? atoi(dbg) : 0;
-    return dispatch_tile(padded_width(kin), padded_width(nout), a, plan->n_tiles, (hipStream_t)stream);
+    return dispatch_tile(padded_width(kin), padded_width(nout), a, plan->n_tiles, plan->chunk, (hipStream_t)stream);
 }
 
 template <int KP, int NP>
@@ -1467,7 +1529,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     const int KP = padded_width(din), NP = padded_width(dout);
     hipStream_t s = (hipStream_t)stream;
     // small graphs: fewer persistent workgroups (>= 16 chunks each), and only their slabs are cleared / summed
-    const int nblocks = plan->n_chunks / 16 < 1 ? 1 : (plan->n_chunks / 16 > kDwBlocks ? kDwBlocks : plan->n_chunks / 16);
+    const int nblocks = plan->n_units / 16 < 1 ? 1 : (plan->n_units / 16 > kDwBlocks ? kDwBlocks : plan->n_units / 16);
     const size_t slab_bytes = sizeof(float) * (size_t)(nblocks + plan->num_relations + 1) * kDwSlabsPer * KP * NP;
     float* bias_slabs = (float*)workspace + dw_slab_floats(plan->num_relations, KP, NP);
     hipError_t e = hipMemsetAsync(workspace, 0, slab_bytes, s);
@@ -1494,12 +1556,13 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.ldg = ldg;
     a.dout4 = (dout + 3) / 4;
     a.tile = plan->tile;
-    a.n_chunks = plan->n_chunks;
+    a.n_units = plan->n_units;
+    a.ushift = plan->chunk == 128 ? 1 : 0;
     a.num_rel = plan->num_relations;
     st = dispatch_dw(KP, NP, a, nblocks, s);
     if (st != RGCN_OK) return st;
     hipLaunchKernelGGL(rgcn_dw_reduce_kernel, dim3(plan->num_relations + 2, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs, a.bias_slabs,
-                       plan->rel_order, plan->chunk_rel, plan->n_chunks, nblocks, plan->num_relations, KP, NP, din,
+                       plan->rel_order, plan->chunk_rel, plan->n_units, a.ushift, nblocks, plan->num_relations, KP, NP, din,
                        dout, d_weight, d_root, d_bias);
     return (int)hipGetLastError();
 }

@@ -53,19 +53,20 @@ class RankPlans:
 
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
-               aggr: str, dctx: DistContext) -> RankPlans:
+               aggr: str, dctx: DistContext, chunk: int = 64) -> RankPlans:
     out = []
     for s in range(dctx.pieces):
         b, e = dctx.node_range(s, n_nodes)
         out.append(build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr,
-                                     fwd_range=(b, e), bwd_range=(b, e)))
+                                     fwd_range=(b, e), bwd_range=(b, e), chunk=chunk))
     return RankPlans(out)
 
 
-def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext) -> RankPlans:
+def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext,
+                      chunk: int = 64) -> RankPlans:
     return cached_graph_plans(
-        edge_index, edge_type, n_nodes, num_relations, tile, aggr,
-        builder=lambda: rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx),
+        edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
+        builder=lambda: rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx, chunk),
         extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, dctx.piece_rows))
 
 

@@ -37,7 +37,9 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-CHUNK = 64  # edge slots per chunk == rows of one LDS ring slot (must match csrc/rgcn_common.h)
+CHUNK = 64  # default edge slots per chunk == rows of one LDS ring slot (csrc/rgcn_common.h kChunk)
+UNIT = 64   # rows the weight-gradient kernels walk at a time: a chunk is chunk // UNIT units
+CHUNKS = (64, 128)   # chunk sizes the kernels are built for
 
 
 @dataclass
@@ -47,6 +49,7 @@ class TilePlan:
     node_end: int         # one past the last owned output node
     num_relations: int    # R' (the root pseudo relation is id R')
     tile: int
+    chunk: int            # edge slots per chunk (64 or 128)
     n_tiles: int
     n_chunks: int
     n_edges: int          # real edges placed (before merging duplicate triples; no root / padding)
@@ -55,12 +58,13 @@ class TilePlan:
     chunk_cnt: Tensor     # int32 [n_chunks]
     chunk_tile: Tensor    # int32 [n_chunks]
     chunk_flags: Tensor   # int32 [n_chunks]  bit t: MFMA row tile t of the chunk holds a repeated destination
-    rel_order: Tensor     # int32 [n_chunks]
-    slot_src: Tensor      # int32 [n_chunks * CHUNK]
-    slot_w: Tensor        # float32 [n_chunks * CHUNK]
-    slot_dstl: Tensor     # int32 [n_chunks * CHUNK]  row inside the tile (padding: tile)
-    slot_row: Tensor      # int32 [n_chunks * CHUNK]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
-    slot_acc: Tensor      # int32 [n_chunks * CHUNK]  run-end position << 24 | accumulator row
+    rel_order: Tensor     # int32 [n_units]  non-empty 64-row units (unit u = rows [64 u, 64 u + 64) of the slot
+                          #   arrays, chunk u // (chunk // 64)), relation-major then tile: the dW kernels' walk
+    slot_src: Tensor      # int32 [n_chunks * chunk]
+    slot_w: Tensor        # float32 [n_chunks * chunk]
+    slot_dstl: Tensor     # int32 [n_chunks * chunk]  row inside the tile (padding: tile)
+    slot_row: Tensor      # int32 [n_chunks * chunk]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
+    slot_acc: Tensor      # int32 [n_chunks * chunk]  run-end position << 24 | accumulator row
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -70,6 +74,10 @@ class TilePlan:
     @property
     def n_owned(self) -> int:
         return self.node_end - self.node_begin
+
+    @property
+    def n_units(self) -> int:
+        return int(self.rel_order.shape[0])
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (
@@ -94,11 +102,15 @@ def edge_weights(src: Tensor, dst: Tensor, rel: Tensor, num_relations: int, aggr
 
 def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes: int,
                num_relations: int, tile: int, node_begin: int = 0,
-               node_end: Optional[int] = None) -> TilePlan:
+               node_end: Optional[int] = None, chunk: int = CHUNK) -> TilePlan:
     """Lay out the edges scattering into ``[node_begin, node_end)``.
 
     gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src).
+    chunk: edge slots per chunk (one of CHUNKS).
     """
+    if chunk not in CHUNKS:
+        raise ValueError(f"chunk must be one of {CHUNKS}")
+    CHUNK = chunk  # noqa: N806  (shadows the module default inside this function)
     if node_end is None:
         node_end = n_nodes
     if node_begin % tile != 0:
@@ -183,10 +195,15 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     per_tile = torch.bincount(chunk_tile.to(torch.int64), minlength=n_tiles)
     tile_ptr = torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev)
     tile_ptr[1:] = torch.cumsum(per_tile, 0).to(torch.int32)
+    # the dW kernels walk 64-row units, relation-major: units of a chunk that hold no row tile are left out
+    upc = CHUNK // UNIT
     order_key = chunk_rel.to(torch.int64) * max(n_tiles, 1) + chunk_tile.to(torch.int64)
-    rel_order = torch.sort(order_key, stable=True)[1].to(torch.int32)
+    chunk_order = torch.sort(order_key, stable=True)[1]
+    units = (chunk_order[:, None] * upc + torch.arange(upc, device=dev)[None, :]).reshape(-1)
+    used = (chunk_cnt.to(torch.int64)[chunk_order][:, None] > UNIT * torch.arange(upc, device=dev)[None, :]).reshape(-1)
+    rel_order = units[used].to(torch.int32)
     return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end,
-                    num_relations=num_relations, tile=tile, n_tiles=n_tiles, n_chunks=n_chunks,
+                    num_relations=num_relations, tile=tile, chunk=CHUNK, n_tiles=n_tiles, n_chunks=n_chunks,
                     n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
                     slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags)
@@ -238,6 +255,49 @@ def choose_tile(n_nodes: int, n_edges: int, num_relations: int, in_channels: int
     return best
 
 
+def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int):
+    """(tile, chunk) for a layer: output nodes per tile and edge slots per chunk.
+
+    Cost model of the forward / dX kernel, calibrated on the 10M-node / 100M-edge graph (tools/debug/stamps.py): a
+    chunk costs ~800 cycles whatever it holds (barrier, metadata, pipeline fill and drain) and every 16-row MFMA tile
+    ~650 (512 of them MFMA issue).  A (tile, relation) group of g = tile * E / (N R') edges (roughly normal, sd
+    sqrt(g)) takes E[ceil(g / chunk)] chunks and ~g / 16 + 1/2 row tiles, so larger tiles and 128-slot chunks
+    amortise the fixed part -- within the LDS: (tile + 1) * (pad(width) + 4) * 4 B of accumulator plus at least two
+    ring slots of chunk * (pad(other width) + 2) * 4 B (three cost nothing extra; with two the producers run only one
+    chunk ahead: +3 %).  128-slot chunks are built for widths <= 64.  Small graphs keep >= 512 tiles (two workgroups
+    per CU) as long as the tile does not drop below 64 nodes, whatever the model says."""
+    import math
+    kp, np_ = padded_width(in_channels), padded_width(out_channels)
+    density = n_edges / max(1.0, float(n_nodes) * max(1, num_relations))
+
+    def lds(t, chunk, ring):
+        fwd = (t + 1) * (np_ + ACC_PAD) * 4 + ring * chunk * (kp + 2) * 4
+        bwd = (t + 1) * (kp + ACC_PAD) * 4 + ring * chunk * (np_ + 2) * 4
+        return max(fwd, bwd)
+
+    def expect_ceil(g, unit):
+        if g <= 0:
+            return 0.0
+        sd = math.sqrt(g)
+        return sum(0.5 * math.erfc((unit * k - g) / (sd * math.sqrt(2.0))) for k in range(0, int(g / unit) + 6))
+
+    def cost(t, chunk):
+        g = density * t
+        ring_penalty = 1.0 if lds(t, chunk, 3) <= LDS_BYTES else 1.03
+        per_rel = expect_ceil(g, chunk) * 800.0 + (g / 16.0 + 0.5) * 650.0 if g > 0 else 0.0
+        root = math.ceil(t / chunk) * 800.0 + (t / 16.0) * 650.0
+        return ring_penalty * (max(1, num_relations) * per_rel + root) / t      # cycles per output node
+
+    cands = [(t, c) for c in CHUNKS for t in range(64, 513, 32)
+             if lds(t, c, 2) <= LDS_BYTES and (c == CHUNK or max(kp, np_) <= 64)]
+    if not cands:
+        return 64, CHUNK
+    few = [tc for tc in cands if n_nodes // tc[0] >= 512]
+    if not few:
+        return min(t for t, _ in cands), CHUNK
+    return min(few, key=lambda tc: (round(cost(*tc), 1), -tc[0]))
+
+
 def run_metadata(slot_dstl: Tensor, tile: int):
     """Per slot, for the forward kernel's run-sum (csrc/rgcn_kernels.hip stage B/C), precomputed here so
     the kernel spends no vector instructions on it: inside every 16-slot MFMA row tile, slots with equal
@@ -271,13 +331,13 @@ class GraphPlans:
 def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
                       tile: int, aggr: str = "mean",
                       fwd_range: Optional[Tuple[int, int]] = None,
-                      bwd_range: Optional[Tuple[int, int]] = None) -> GraphPlans:
+                      bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK) -> GraphPlans:
     src, dst = edge_index[0], edge_index[1]
     w = edge_weights(src, dst, edge_type, num_relations, aggr)
     fb, fe = fwd_range if fwd_range is not None else (0, n_nodes)
     bb, be = bwd_range if bwd_range is not None else (0, n_nodes)
-    fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe)
-    bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be)
+    fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe, chunk)
+    bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be, chunk)
     return GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(edge_type.shape[0]))
 
 
@@ -306,14 +366,14 @@ _CACHE_MAX = 16
 
 
 def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
-                       tile: int, aggr: str, builder=None, extra_key=()) -> GraphPlans:
+                       tile: int, aggr: str, builder=None, extra_key=(), chunk: int = CHUNK) -> GraphPlans:
     key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
-           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, aggr) + tuple(extra_key)
+           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr) + tuple(extra_key)
     hit = _CACHE.get(key)
     if hit is not None:
         return hit[0]
     if builder is None:
-        plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr)
+        plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk)
     else:
         plans = builder()
     if len(_CACHE) >= _CACHE_MAX:

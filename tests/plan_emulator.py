@@ -5,13 +5,12 @@ dW kernel     : dWp[rel] += (w * x[src])^T @ g[tile*T + dstl]
 where Wp = concat(weight[R'], root[None]) -- the root is relation id R'."""
 import numpy as np
 
-from scaling_rgcn_training_amd.plan import CHUNK
 
 
 def _slots(plan):
     src = plan.slot_src.cpu().numpy().astype(np.int64)
     w = plan.slot_w.cpu().numpy().astype(np.float64)
-    rel = np.repeat(plan.chunk_rel.cpu().numpy().astype(np.int64), CHUNK)
+    rel = np.repeat(plan.chunk_rel.cpu().numpy().astype(np.int64), plan.chunk)
     valid = src < plan.n_nodes
     node = plan.slot_row.cpu().numpy().astype(np.int64)  # row of the owned range (local to node_begin)
     return src, w, rel, node, valid
@@ -32,12 +31,23 @@ def emulate_spmm(plan, x, w_all, bias=None):
 
 
 def emulate_dw(plan, x, g_owned, n_rel_all, din, dout):
+    """The weight-gradient kernels' walk: 64-row units in ``rel_order`` (relation-major); a unit's relation and
+    row count come from its chunk."""
     src, w, rel, node, valid = _slots(plan)
     x = np.asarray(x, np.float64)
     g = np.asarray(g_owned, np.float64)
     dw = np.zeros((n_rel_all, din, dout))
-    for r in range(n_rel_all):
-        sel = valid & (rel == r)
-        if sel.any():
-            dw[r] = (x[src[sel]] * w[sel, None]).T @ g[node[sel]]
+    upc = plan.chunk // 64
+    cnt = plan.chunk_cnt.cpu().numpy().astype(np.int64)
+    crel = plan.chunk_rel.cpu().numpy().astype(np.int64)
+    seen = np.zeros(src.shape[0], bool)
+    for u in plan.rel_order.cpu().numpy().astype(np.int64):
+        chunk, h = u // upc, u % upc
+        n = min(max(cnt[chunk] - 64 * h, 0), 64)
+        assert n > 0, "empty unit in rel_order"
+        rows = np.arange(64 * u, 64 * u + n)
+        seen[rows] = True
+        sel = rows[valid[rows]]
+        dw[crel[chunk]] += (x[src[sel]] * w[sel, None]).T @ g[node[sel]]
+    assert not (valid & ~seen).any(), "rel_order misses slots"
     return dw

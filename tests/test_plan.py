@@ -9,10 +9,10 @@ from scaling_rgcn_training_amd import plan as P
 from tests.plan_emulator import emulate_dw, emulate_spmm
 
 
-def _plans_from_golden(g, tile):
+def _plans_from_golden(g, tile, chunk=64):
     ei = torch.from_numpy(g["edge_index"]).long()
     et = torch.from_numpy(g["edge_type"]).long()
-    return P.build_graph_plans(ei, et, int(g["num_nodes"]), int(g["num_relations"]), tile)
+    return P.build_graph_plans(ei, et, int(g["num_nodes"]), int(g["num_relations"]), tile, chunk=chunk)
 
 
 def _distinct(ei, et, n, r):
@@ -21,7 +21,7 @@ def _distinct(ei, et, n, r):
 
 
 def _check_invariants(plan, n_real_edges):
-    c = P.CHUNK
+    c = plan.chunk
     assert plan.slot_src.numel() == plan.n_chunks * c
     src = plan.slot_src.view(-1, 16)
     valid = src < plan.n_nodes
@@ -61,18 +61,21 @@ def _check_invariants(plan, n_real_edges):
         rels = plan.chunk_rel[tp[t]:tp[t + 1]]
         assert torch.all(plan.chunk_tile[tp[t]:tp[t + 1]] == t)
         assert torch.all(rels[1:] >= rels[:-1]) and rels[-1] == plan.num_relations
+    # the dW walk: every 64-row unit that holds a row tile exactly once, relation-major
     ro = plan.rel_order.long()
-    assert sorted(ro.tolist()) == list(range(plan.n_chunks))
-    assert torch.all(plan.chunk_rel[ro][1:] >= plan.chunk_rel[ro][:-1])
+    upc = c // 64
+    want = [ch * upc + h for ch in range(plan.n_chunks) for h in range(upc) if int(cnt[ch]) > 64 * h]
+    assert sorted(ro.tolist()) == want and plan.n_units == len(want)
+    assert torch.all(plan.chunk_rel[ro // upc][1:] >= plan.chunk_rel[ro // upc][:-1])
 
 
-@pytest.mark.parametrize("tile", [4, 64, 256])
-def test_plan_walk_matches_golden(golden, tile):
+@pytest.mark.parametrize("tile,chunk", [(4, 64), (64, 64), (256, 64), (64, 128), (256, 128)])
+def test_plan_walk_matches_golden(golden, tile, chunk):
     if str(golden["mode"]) != "full":
         pytest.skip("plan is weight-mode independent")
     if tile == 4 and golden["edge_index"].shape[1] > 2000:
         pytest.skip("tiny tiles only on small graphs")
-    plans = _plans_from_golden(golden, tile)
+    plans = _plans_from_golden(golden, tile, chunk)
     e = _distinct(golden["edge_index"], golden["edge_type"], int(golden["num_nodes"]), int(golden["num_relations"]))
     _check_invariants(plans.fwd, e)
     _check_invariants(plans.bwd, e)

@@ -18,10 +18,11 @@ n, e = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda:0")
 ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, 32, 64, 64, dev)
 tile = int(os.environ.get("RGCN_TILE", P.choose_tile(n, e, 32, 64, 64)))
-plans = P.build_graph_plans(ei, et, n, 32, tile)
+chunk = int(os.environ.get('RGCN_CHUNK', 64))
+plans = P.build_graph_plans(ei, et, n, 32, tile, chunk=chunk)
 print("tile", tile)
 fp = plans.fwd
-stamps = torch.zeros(max(fp.n_tiles, 1024) * 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(max(fp.n_tiles, 1024) * 32, dtype=torch.int64, device=dev)
 lib.rgcn_debug_set_stamps.argtypes = [ctypes.c_void_p]
 assert lib.rgcn_debug_set_stamps(stamps.data_ptr()) == 0
 out = torch.empty(n, 64, device=dev)
@@ -36,7 +37,7 @@ else:
         _lib.bwd_dw(_lib.plan_struct(fp), x, 64, dg, 64, dwt, drt, dbt)
 torch.cuda.synchronize()
 print("kernel:", which)
-s = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64)
+s = stamps.cpu().numpy().reshape(-1, 32).astype(np.float64)
 if which == 'fwd':
     s = s[:fp.n_tiles]
 nch = s[:, 7]
@@ -47,6 +48,6 @@ for i, nm in enumerate(names):
     print(f"{nm:20s} {s[:, i].sum() / nch.sum():9.1f} cycles/chunk")
 print(f"consumer loop total {tot_c.sum() / nch.sum():9.1f} cycles/chunk; producer wave0 loop total {tot_p.sum() / nch.sum():9.1f}")
 if which == "fwd":
-    for i in range(4):
-        c = s[:, 12 + i].sum()
+    for i in range(8):
+        c = s[:, 16 + i].sum()
         print(f"chunks with {i + 1} row tiles: {int(c):9d}  compute {s[:, 8 + i].sum() / max(c, 1):8.1f} cycles/chunk")
