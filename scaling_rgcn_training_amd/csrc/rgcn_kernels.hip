@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int kDwSlabsPer = 4;  // partial slabs per (workgroup, relation): one per consumer wave in the wide kernel
-constexpr int kWideConsumers = 4;  // wide dW kernel: two consumer waves per SIMD (64x64), so one fills the other's stalls
+constexpr int kWideConsumers = 4;  // wide dW kernel: one consumer wave per SIMD
 
 struct DwArgs {
     const int* rel_order;
@@ -1081,49 +1081,83 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
                 f32x4 g4[UB];
                 float wv;
             };
+            // this lane's row of group 0; group g is 16 rows further (immediate offsets)
+            const float* hrow = hb + (4 * cw + kq) * KP;
+            const float* grow = gb + (4 * cw + kq) * NP;
+            const float* wrow = wb + 4 * cw + kq;
             auto load_grp = [&](Grp& o, int g) {
-                const int row = 16 * g + 4 * cw + kq;
-                o.wv = wb[row];
+                o.wv = wrow[16 * g];
 #pragma unroll
-                for (int u = 0; u < UA; ++u) o.a4[u] = *(const f32x4*)(hb + row * KP + 64 * u);
+                for (int u = 0; u < UA; ++u) o.a4[u] = *(const f32x4*)(hrow + 16 * g * KP + 64 * u);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) o.g4[u] = *(const f32x4*)(gb + row * NP + 64 * u);
+                for (int u = 0; u < UB; ++u) o.g4[u] = *(const f32x4*)(grow + 16 * g * NP + 64 * u);
             };
-            auto compute_grp = [&](const Grp& o) {
-                float bv[NB];
+            // One group = 16 MFMAs accumulating IN PLACE.  The MFMA is issued through inline asm with the accumulator
+            // as a tied "+v" operand: with the builtin (destination free to differ from the C operand) hipcc gives the
+            // guarded group blocks different accumulator registers and moves all 64 of them at every merge (60+
+            // v_mov per chunk, each costing MFMA issue time).  What the compiler therefore does not see is the MFMA
+            // result hazard: the accumulators are only read by flush(), a workgroup barrier and a scalar-load round
+            // trip after the last MFMA that wrote them.  `next` (when given) is read in between the MFMAs: an LDS
+            // instruction there costs ~2 cycles and has the rest of the block to land.
+            auto compute_grp = [&](const Grp& o, Grp* next, int gnext) {
+                f32x4 bv4[UB];
 #pragma unroll
-                for (int jb = 0; jb < NB; ++jb) {
-                    const float gv = o.g4[jb >> 2][jb & 3];
-                    if (is_root) bsum[jb] += gv;
-                    bv[jb] = gv * o.wv;
+                for (int u = 0; u < UB; ++u) {
+                    bv4[u] = o.g4[u] * o.wv;
+                    asm volatile("" : "+v"(bv4[u]));      // all multiplies in ONE group in front of the MFMAs
                 }
+                int n = 0;
 #pragma unroll
                 for (int ia = 0; ia < NA; ++ia)
 #pragma unroll
                     for (int jb = 0; jb < NB; ++jb) {
                         if (RGCN_ABL & 1) {   // diagnostic build: no MFMA
-                            acc[ia][jb][0] += o.a4[ia >> 2][ia & 3] * bv[jb];
+                            acc[ia][jb][0] += o.a4[ia >> 2][ia & 3] * bv4[jb >> 2][jb & 3];
                             continue;
                         }
-                        acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a4[ia >> 2][ia & 3], bv[jb], acc[ia][jb], 0, 0, 0);
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                                     : "+v"(acc[ia][jb])
+                                     : "v"(o.a4[ia >> 2][ia & 3]), "v"(bv4[jb >> 2][jb & 3]));
+                        ++n;
+                        if (next != nullptr && n == 2) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            load_grp(*next, gnext);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
+                __builtin_amdgcn_sched_barrier(0);
             };
             const int ngrp = (cnt + 15) >> 4;
-            // this team's groups: g0, g0 + TEAMS, ...; the starting team alternates with the chunk so that
-            // chunks with an odd number of groups load both teams evenly
-            const int g0 = (team + it) % TEAMS;
-            Grp grp[2];
-            if (g0 < ngrp) load_grp(grp[0], g0);
-            __builtin_amdgcn_sched_barrier(0);
+            static_assert(TEAMS == 1, "one team of four consumer waves (two teams were tried: no gain)");
+            {
+                // Ping-pong operand sets: group g + 1's operands are read INSIDE group g's MFMA block (LDS instructions
+                // between MFMAs are nearly free and their round trip is covered).  Four guarded blocks in a row on
+                // purpose: with one straight-line variant per group count (a switch), or with nested guards, the
+                // register allocator moves the 64 accumulator registers at the merges.  The read one group past the
+                // chunk's last is unconditional (no select / copy of the operand set) and harmless: still inside the
+                // rings, never used.
+                Grp grp[2];
+                load_grp(grp[0], 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int gi = 0; gi < kChunk / 16 / TEAMS; ++gi) {
-                const int g = g0 + gi * TEAMS;
-                if (g < ngrp) {
-                    if (g + TEAMS < ngrp) {
-                        load_grp(grp[(gi + 1) & 1], g + TEAMS);
-                        __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < kChunk / 16; ++g) {          // unrolled: every LDS offset is an immediate
+                    if (g < ngrp) compute_grp(grp[g & 1], g + 1 < kChunk / 16 ? &grp[(g + 1) & 1] : nullptr, g + 1);
+                }
+                // Root chunks also feed the bias gradient: a separate pass over the chunk's dOut rows.  Folding it into
+                // the MFMA loop costs either 8 selects per group on every chunk or a second copy of the loop, and at
+                // the merge of two loop copies the register allocator moves all 64 accumulator registers.
+                if (is_root) {
+#pragma unroll
+                    for (int g = 0; g < kChunk / 16; ++g) {
+                        if (g < ngrp) {
+#pragma unroll
+                            for (int u = 0; u < UB; ++u) {
+                                const f32x4 gv = *(const f32x4*)(grow + 16 * g * NP + 64 * u);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) bsum[4 * u + c] += gv[c];
+                            }
+                        }
                     }
-                    compute_grp(grp[gi & 1]);
                 }
             }
             STAMP(t2);
