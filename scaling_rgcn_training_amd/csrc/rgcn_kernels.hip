@@ -802,9 +802,12 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
             const int c = ldc(a.chunk_cnt, unit >> a.ushift) - kChunk * (unit & ((1 << a.ushift) - 1));
             return c < kChunk ? c : kChunk;
         };
+        // two-deep: the unit id is fetched TWO iterations ahead and its metadata one ahead, so no scalar load waits
+        // for another one issued in the same iteration (that dependent round trip was ~450 cycles per chunk)
         int chunk_pre = ldc(a.rel_order, i0);
         int cnt_pre = unit_cnt(chunk_pre);
         int relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
+        int unit_next = ldc(a.rel_order, i0 + (nch > 1 ? 1 : 0));
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bar = 0;
@@ -815,10 +818,10 @@ __global__ void __launch_bounds__(kThreads, 2) rgcn_dw_kernel(const DwArgs a) {
             const int cnt = cnt_pre;
             const int rel = relv_pre;
             if (it + 1 < nch) {
-                chunk_pre = ldc(a.rel_order, i0 + it + 1);
-                cnt_pre = unit_cnt(chunk_pre);
-                relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
+                cnt_pre = unit_cnt(unit_next);
+                relv_pre = ldc(a.chunk_rel, unit_next >> a.ushift);
             }
+            unit_next = ldc(a.rel_order, i0 + (it + 2 < nch ? it + 2 : nch - 1));
             STAMP(t1);
             if (rel != rel_cur) {
                 if (rel_cur >= 0) flush();
@@ -988,9 +991,11 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
     static_assert(CONS <= kDwSlabsPer, "one partial slab per consumer wave");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ringh = lds;                                   // [NBUF][64][KP]
+    // small arrays first: their LDS addresses stay below 64 KiB, i.e. inside the immediate-offset field of the
+    // DS instructions (an address beyond it costs a vector add per access)
+    float* wring = lds;                                   // [NBUF][64]; then the index rings [2][2D+1][64]
+    float* ringh = wring + (NBUF + 2 * (2 * D + 1)) * kChunk;   // [NBUF][64][KP]
     float* ringg = ringh + NBUF * kChunk * KP;            // [NBUF][64][NP]
-    float* wring = ringg + NBUF * kChunk * NP;            // [NBUF][64]; then the index rings [2][2D+1][64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1046,9 +1051,12 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
             const int c = ldc(a.chunk_cnt, unit >> a.ushift) - kChunk * (unit & ((1 << a.ushift) - 1));
             return c < kChunk ? c : kChunk;
         };
+        // two-deep: the unit id is fetched TWO iterations ahead and its metadata one ahead, so no scalar load waits
+        // for another one issued in the same iteration (that dependent round trip was ~450 cycles per chunk)
         int chunk_pre = ldc(a.rel_order, i0);
         int cnt_pre = unit_cnt(chunk_pre);
         int relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
+        int unit_next = ldc(a.rel_order, i0 + (nch > 1 ? 1 : 0));
         wg_barrier();   // producers: index vectors landed
         wg_barrier();   // producers: chunk 0 landed
 #ifdef RGCN_STAMPS
@@ -1060,10 +1068,10 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
             const int cnt = cnt_pre;
             const int rel = relv_pre;
             if (it + 1 < nch) {
-                chunk_pre = ldc(a.rel_order, i0 + it + 1);
-                cnt_pre = unit_cnt(chunk_pre);
-                relv_pre = ldc(a.chunk_rel, chunk_pre >> a.ushift);
+                cnt_pre = unit_cnt(unit_next);
+                relv_pre = ldc(a.chunk_rel, unit_next >> a.ushift);
             }
+            unit_next = ldc(a.rel_order, i0 + (it + 2 < nch ? it + 2 : nch - 1));
             STAMP(t1);
             if (rel != rel_cur) {
                 if (rel_cur >= 0) flush();
