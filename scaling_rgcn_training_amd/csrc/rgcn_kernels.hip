@@ -156,6 +156,34 @@ struct RowGather {
         }
     }
 
+    // NOPS_PART consecutive DMA instructions of a 64-row block, starting at instruction `op0` (a multiple of V, so
+    // that instruction i uses the lane constants i % V): rows op0 * RPI .. of the block whose 64 row indices are in
+    // `idxv`.  part_base = LDS address of the first of those rows.
+    template <int NOPS_PART>
+    __device__ __forceinline__ void issue_part(const float* __restrict__ base, unsigned bytes, int n_rows, int ld,
+                                               int idxv, float* part_base, int op0) const {
+        int idx[NOPS_PART];
+        const int pa = perm_addr + op0 * RPI * 4;
+#pragma unroll
+        for (int i = 0; i < NOPS_PART; ++i) idx[i] = __builtin_amdgcn_ds_bpermute(pa + i * RPI * 4, idxv);
+        if constexpr (BUF) {
+            const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, bytes);
+#pragma unroll
+            for (int i = 0; i < NOPS_PART; ++i) {
+                const unsigned off = __umul24((unsigned)idx[i], rowb[i % V]) + coff[i % V];
+                dma16_buf(rsrc, off, part_base + i * RPI * W);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NOPS_PART; ++i) {
+                const unsigned co = coff[i % V];
+                const float* gp = (idx[i] < n_rows && co != 0xFFFFFFF0u)
+                                      ? (const float*)((const char*)(base + (size_t)idx[i] * ld) + co) : g_zero16;
+                dma16(gp, part_base + i * RPI * W);
+            }
+        }
+    }
+
     __device__ __forceinline__ void issue(const float* __restrict__ base, unsigned bytes, int n_rows, int ld,
                                           int idxv, float* slot_base) const {
         // all cross-lane index fetches first (one LDS-crossbar round trip for the batch, not one per DMA);
@@ -376,21 +404,30 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
                 f32x4 old[SL];    // Y^T path: accumulator contents (y, z = the two MFMA chains)
                 float* dst[4];    // accumulator rows this lane updates (Y^T path: dst[0] only)
             };
+            // this lane's operand addresses for row tile 0 of the part, formed once; row tile rt is rt * 16 rows
+            // further, an immediate offset of the DS instruction (left to itself hipcc re-derives every address
+            // per tile: 5 vector adds each)
+            const float* arow[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
+                arow[j] = hb + rowl * KP + pos * 4;
+            }
+            const float* wrow = wb + rowl;
+            const int* drow = db + rowl;
+            const float* wrow4 = wb + 4 * kq;
+            const int* drow4 = db + 4 * kq;
             auto load_ops = [&](Ops& o, int rt, auto tr_c) {
-                const int row = rt * 16 + rowl;
                 // weight / metadata first: the accumulator address of the tile is the first thing computed from it
                 if constexpr (decltype(tr_c)::value) {
-                    o.w1 = wb[rt * 16 + rowl];
-                    o.d1 = db[rt * 16 + rowl];
+                    o.w1 = wrow[rt * 16];
+                    o.d1 = drow[rt * 16];
                 } else {
-                    o.w4 = *(const f32x4*)(wb + rt * 16 + 4 * kq);
-                    o.d4 = *(const i32x4*)(db + rt * 16 + 4 * kq);
+                    o.w4 = *(const f32x4*)(wrow4 + rt * 16);
+                    o.d4 = *(const i32x4*)(drow4 + rt * 16);
                 }
 #pragma unroll
-                for (int j = 0; j < KT; ++j) {
-                    const int pos = (4 * j + kq) ^ swizzle<kRowRead, LPR>(rowl);
-                    o.av[j] = *(const f32x4*)(hb + row * KP + pos * 4);
-                }
+                for (int j = 0; j < KT; ++j) o.av[j] = *(const f32x4*)(arow[j] + rt * 16 * KP);
             };
             // accumulator row (low 24 bits of the plan's metadata word) -> LDS address of this lane's column(s):
             // one v_mad_u32_u24 (it ignores the run-end byte on top by itself)
@@ -533,7 +570,15 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
                         if (step > NRT) continue;
                         // first half of this tile's MFMAs, the next tile's operand reads in between (an LDS
                         // instruction between two MFMAs costs ~2 cycles; in front of the block its full issue slot)
-                        if (step + 1 < NRT) load_ops(ops[step + 1], step + 1, tr_c);
+                        if (step + 1 < NRT) {
+                            if (RGCN_ABL & 4) {     // diagnostic: no operand reads after tile 0 (opaque copy: no CSE)
+                                ops[step + 1] = ops[0];
+#pragma unroll
+                                for (int j = 0; j < KT; ++j) asm volatile("" : "+v"(ops[step + 1].av[j]));
+                            } else {
+                                load_ops(ops[step + 1], step + 1, tr_c);
+                            }
+                        }
                         if (step < NRT) stage_a_t(ops[step], tl[step], 0);
                         if (step + 1 < NRT) {
 #pragma unroll
@@ -639,6 +684,56 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
         int knext = pw;                                   // this wave's next chunk
         RowGather<KP, kRowRead, BUF> gather;
         gather.init(lane, (a.dbg & 2) ? 0 : a.din4, a.ldx);
+#ifdef RGCN_STAMPS
+        unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
+#endif
+        using Gather = RowGather<KP, kRowRead, BUF>;
+        constexpr int RW = CH / kTileProducers;           // rows of a chunk per producer wave in the spread scheme
+        if constexpr (D == 1 && RW >= 16 && RW <= 64 && RW % Gather::RPI == 0) {
+            // ---- one chunk ahead (two ring slots): EVERY wave issues its RW rows of EVERY chunk -------------------
+            // With a single chunk in flight its round trip is on the critical path of every iteration; four waves
+            // issuing a quarter each put the whole chunk on the wire in a quarter of the time (and spread the
+            // producers' vector instructions over the four SIMDs instead of loading one consumer's).
+            constexpr int NOPS_PART = RW / Gather::RPI;
+            const int row0 = pw * RW;                     // first row of this wave's part inside the chunk
+            const int half = row0 / 64, op0 = (row0 % 64) / Gather::RPI;
+            const bool meta = row0 % 64 == 0;             // this wave also moves the half's weights / run metadata
+            auto load_idx = [&](int k) {
+                const int kk = k < nch ? k : nch - 1;
+                return a.slot_src[(size_t)(c0 + kk) * CH + 64 * half + lane];
+            };
+            auto issue_part = [&](int k, int idxv) {
+                const int chunk = c0 + k, buf = k % NBUF;
+                gather.template issue_part<NOPS_PART>(a.x, a.x_bytes, a.n_rows, a.ldx, idxv,
+                                                      ring + (buf * CH + row0) * KP, op0);
+                if (meta) {
+                    dma4(a.slot_w + (size_t)chunk * CH + 64 * half + lane, wring + buf * CH + 64 * half);
+                    dma4(a.slot_acc + (size_t)chunk * CH + 64 * half + lane, dring + buf * CH + 64 * half);
+                }
+            };
+            int idx_cur = load_idx(0);
+            issue_part(0, idx_cur);                       // (its index vector is waited for here, once per tile)
+            idx_cur = load_idx(1);
+            wait_vmcnt<0>();                              // chunk 0 landed (and the indices of chunk 1)
+            wg_barrier();                                 // chunk 0 (and the accumulator init) visible
+            for (int it = 0; it < nch; ++it) {
+                STAMP(p0);
+                int idx_next = idx_cur;
+                if (it + 1 < nch) {
+                    issue_part(it + 1, idx_cur);
+                    idx_next = load_idx(it + 2);          // youngest operation: lands with the rows
+                }
+                STAMP(p1);
+                wait_vmcnt<0>();                          // chunk it + 1 landed
+                idx_cur = idx_next;
+                STAMP(p2);
+                wg_barrier();
+                STAMP(p3);
+                STAMP_ADD(sp_issue, p0, p1);
+                STAMP_ADD(sp_wait, p1, p2);
+                STAMP_ADD(sp_bar, p2, p3);
+            }
+        } else {
         // Row indices of this wave's NEXT chunk: one coalesced load, issued right after the current
         // chunk's DMAs and not touched until the wave's next turn 4 iterations later (any use here would
         // make hipcc wait vmcnt(0) on the spot, i.e. for the DMAs just issued).  The address is clamped
@@ -668,9 +763,6 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             if (k % kTileProducers == pw && k < nch) issue(k);
         if (pw == 0) wait_vmcnt<0>();                     // chunk 0 landed
         wg_barrier();                                     // chunk 0 (and the accumulator init) visible
-#ifdef RGCN_STAMPS
-        unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
-#endif
         for (int it = 0; it < nch; ++it) {
             // slot (it+D)%NBUF held chunk it-1, which the consumers finished before the last barrier
             const int ki = it + D, kw = it + 1;
@@ -686,6 +778,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             STAMP_ADD(sp_issue, p0, p1);
             STAMP_ADD(sp_wait, p1, p2);
             STAMP_ADD(sp_bar, p2, p3);
+        }
         }
         wait_vmcnt<0>();
 #ifdef RGCN_STAMPS
