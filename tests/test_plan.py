@@ -182,3 +182,42 @@ def test_plan_cache_identity():
     ei2 = ei.clone()
     c = P.cached_graph_plans(ei2, et, 100, 3, 16, "mean")
     assert c is not a
+
+
+def test_plan_walk_random_graphs_property():
+    """hypothesis: any small multigraph (duplicates, self loops, empty relations, isolated nodes), any tile / chunk
+    size: the plans walked the way the kernels walk them reproduce the dense float64 evaluation of the layer
+    (to the fp32 rounding of the plan's edge weights)."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(n=st.integers(1, 70), e=st.integers(0, 400), r=st.integers(1, 6), tile=st.sampled_from([16, 32, 48, 64]),
+           chunk=st.sampled_from([64, 128]), seed=st.integers(0, 10_000), hub=st.booleans())
+    def run(n, e, r, tile, chunk, seed, hub):
+        g = torch.Generator().manual_seed(seed)
+        ei = torch.randint(0, n, (2, e), generator=g)
+        et = torch.randint(0, r, (e,), generator=g)
+        if hub and e > 8:
+            ei[1, : e // 2] = ei[1, 0]          # half the edges into one node
+            et[: e // 4] = et[0]                # many of them in one relation (runs longer than a row tile)
+        din, dout = 5, 3
+        x = torch.randn(n, din, generator=g, dtype=torch.float64)
+        w = torch.randn(r, din, dout, generator=g, dtype=torch.float64)
+        root = torch.randn(din, dout, generator=g, dtype=torch.float64)
+        bias = torch.randn(dout, generator=g, dtype=torch.float64)
+        dg = torch.randn(n, dout, generator=g, dtype=torch.float64)
+        plans = P.build_graph_plans(ei, et, n, r, tile, chunk=chunk)
+        _check_invariants(plans.fwd, _distinct(ei, et, n, r))
+        _check_invariants(plans.bwd, _distinct(ei, et, n, r))
+        ref = O.rgcn_conv_dense(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy())
+        grads = O.rgcn_conv_grads_dense(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), dg.numpy())
+        w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0)
+        np.testing.assert_allclose(emulate_spmm(plans.fwd, x.numpy(), w_all, bias.numpy()), ref, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(emulate_spmm(plans.bwd, dg.numpy(), np.transpose(w_all, (0, 2, 1))), grads["x"],
+                                   rtol=2e-6, atol=2e-6)
+        dw = emulate_dw(plans.fwd, x.numpy(), dg.numpy(), r + 1, din, dout)
+        np.testing.assert_allclose(dw[:-1], grads["weight"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(dw[-1], grads["root"], rtol=2e-6, atol=2e-6)
+
+    run()
