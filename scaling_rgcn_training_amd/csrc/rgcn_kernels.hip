@@ -1207,6 +1207,8 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
                     bv4[u] = o.g4[u] * o.wv;
                     asm volatile("" : "+v"(bv4[u]));      // all multiplies in ONE group in front of the MFMAs
                 }
+                // the MFMAs below are inline asm: the compiler does not see a VALU-write -> MFMA-read hazard
+                asm volatile("s_nop 4" ::: "memory");
                 int n = 0;
 #pragma unroll
                 for (int ia = 0; ia < NA; ++ia)
@@ -1361,6 +1363,171 @@ __global__ void __launch_bounds__(64 * (kProducerWaves + CONS), (kProducerWaves 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel, direct form (64 x 64, buffer-addressable operands)
+// ------------------------------------------------------------------------------------------------
+// In dW every gathered row is used by exactly ONE wave (a wave owns whole rows, see the wide kernel), so staging the
+// rows in LDS buys no reuse -- and LDS-DMA gathers top out at ~25 GB/s per CU (~6.4 TB/s per chip), which is where the
+// wide kernel sits with its two gathered rows per slot.  Here there are no producers, no LDS and no barriers: each
+// wave walks its own range of 64-row units and loads its MFMA operands straight from global memory into registers
+// (buffer_load_dwordx4 by slot index, padding rows out of range -> zeros), half a unit (8 k-steps = 16 loads of 16 B
+// per lane) ahead of the half it is multiplying, with two waves per SIMD to cover the rest of the latency.  Row
+// indices and weights of a unit are one coalesced load each, a whole unit ahead, and reach the lanes that need them
+// through ds_bpermute.  Same arithmetic, same slab layout and the same reduce kernel as the wide form.
+__global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) {
+    constexpr int KP = 64, NP = 64;
+    constexpr int HS = 8;                        // k-steps (4 rows each) per half unit
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int bi0 = (int)((long)b * a.n_units / nb), bi1 = (int)((long)(b + 1) * a.n_units / nb);
+    const int i0 = bi0 + (int)((long)wave * (bi1 - bi0) / 4), i1 = bi0 + (int)((long)(wave + 1) * (bi1 - bi0) / 4);
+    const int nun = i1 - i0;
+    if (nun <= 0) return;
+    const int ml = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rg = make_rsrc(a.g, a.g_bytes);
+    const unsigned colb = 16u * (unsigned)ml;
+    const unsigned rbx = (unsigned)a.ldx * 4u, rbg = (unsigned)a.ldg * 4u;
+    const int perm = kq * 4;                     // ds_bpermute address of row kq of a k-step (further steps: +16 each)
+
+    f32x4 acc[4][4];
+    float bsum[4];
+    int rel_cur = -1;
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            bsum[jb] = 0.f;
+#pragma unroll
+            for (int ia = 0; ia < 4; ++ia) acc[ia][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto flush = [&]() {
+        float* slab = a.slabs + ((size_t)(b + rel_cur) * kDwSlabsPer + wave) * (KP * NP);
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(4 * (4 * kq + r) + ia) * NP + 4 * ml + jb] = acc[ia][jb][r];
+        if (rel_cur == a.num_rel) {
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                float v = bsum[jb];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (kq == 0) a.bias_slabs[((size_t)b * kDwSlabsPer + wave) * NP + 4 * ml + jb] = v;
+            }
+        }
+    };
+    zero_acc();
+
+    struct Idx {      // lane l: slot l of the unit
+        int h, g;
+        float w;
+    };
+    struct Half {
+        f32x4 a4[HS], g4[HS];
+    };
+    auto unit_of = [&](int k) { return ldc(a.rel_order, i0 + (k < nun ? k : nun - 1)); };
+    auto unit_cnt = [&](int unit) {
+        const int cc = ldc(a.chunk_cnt, unit >> a.ushift);
+        const int c = cc - kChunk * (unit & ((1 << a.ushift) - 1));
+        return c < kChunk ? c : kChunk;
+    };
+    auto load_idx = [&](int unit) {
+        const size_t base = (size_t)unit * kChunk + lane;
+        return Idx{a.slot_src[base], a.slot_row[base], a.slot_w[base]};
+    };
+    auto issue_half = [&](Half& o, const Idx& ix, int h) {
+        int ih[HS], ig[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            ih[s] = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), ix.h);
+            ig[s] = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), ix.g);
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            o.a4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)ih[s], rbx) + colb), 0, 0));
+            o.g4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(__umul24((unsigned)ig[s], rbg) + colb), 0, 0));
+        }
+    };
+    // groups g0, g0 + 1 of the unit (two k-step quadruples of this half), guarded by the unit's group count
+    auto compute_half = [&](const Half& o, const Idx& ix, int h, int ngrp, bool is_root) {
+        float wv[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s)
+            wv[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), __builtin_bit_cast(int, ix.w)));
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            if (2 * h + gi < ngrp) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int s = 4 * gi + t;
+                    f32x4 bv = o.g4[s] * wv[s];
+                    // the MFMAs below are inline asm: the compiler does not see a VALU-write -> MFMA-read hazard and
+                    // would schedule the last multiply right in front of the first MFMA (wrong acc[0][0] without this)
+                    asm volatile("s_nop 4" : "+v"(bv));
+#pragma unroll
+                    for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb)
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                                         : "+v"(acc[ia][jb])
+                                         : "v"(o.a4[s][ia]), "v"(bv[jb]));
+                }
+                if (is_root) {      // bias gradient: plain column sums of the root rows
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) bsum[c] += o.g4[4 * gi + t][c];
+                }
+            }
+        }
+    };
+
+    // prologue: ids of units 0..2, indices of units 0 and 1, rows of the first half of unit 0
+    int uid_cur = unit_of(0), uid_nxt = unit_of(1), uid_nn = unit_of(2);
+    int cnt_pre = unit_cnt(uid_cur), rel_pre = ldc(a.chunk_rel, uid_cur >> a.ushift);
+    Idx ix_cur = load_idx(uid_cur), ix_nxt = load_idx(uid_nxt);
+    Half s0, s1;
+    issue_half(s0, ix_cur, 0);
+    for (int k = 0; k < nun; ++k) {
+        const int cnt = cnt_pre, rel = rel_pre;
+        cnt_pre = unit_cnt(uid_nxt);
+        rel_pre = ldc(a.chunk_rel, uid_nxt >> a.ushift);
+        if (rel != rel_cur) {
+            if (rel_cur >= 0) {
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // asm MFMA results -> compiler-scheduled stores
+                flush();
+            }
+            zero_acc();
+            rel_cur = rel;
+        }
+        const bool is_root = rel == a.num_rel;
+        const int ngrp = (cnt + 15) >> 4;
+        // second half of this unit on its way while the first is multiplied
+        issue_half(s1, ix_cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_half(s0, ix_cur, 0, ngrp, is_root);
+        __builtin_amdgcn_sched_barrier(0);
+        // indices of the unit after next, first half of the next unit
+        const Idx ix_nn = load_idx(uid_nn);
+        issue_half(s0, ix_nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_half(s1, ix_cur, 1, ngrp, is_root);
+        __builtin_amdgcn_sched_barrier(0);
+        ix_cur = ix_nxt;
+        ix_nxt = ix_nn;
+        uid_cur = uid_nxt;
+        uid_nxt = uid_nn;
+        uid_nn = unit_of(k + 3);
+    }
+    // the accumulators are read by plain stores the compiler schedules: keep them clear of the last asm MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (rel_cur >= 0) flush();
+}
+
 // slabs -> gradients, fixed summation order (block index ascending) => bitwise reproducible.
 // grid = (R' + 2, parts): blockIdx.x = relation (R' = root, R'+1 = bias), blockIdx.y = slice of the elements.
 // The workgroups whose chunk range touches relation r are a contiguous run [b_lo, b_hi].
@@ -1412,7 +1579,10 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
 // ------------------------------------------------------------------------------------------------
 // host side: argument checks, LDS sizing, dispatch over the padded widths
 // ------------------------------------------------------------------------------------------------
-constexpr int kDwBlocks = 256;  // one workgroup per CU (LDS-bound occupancy), persistent over its chunk range
+constexpr int kDwBlocks = 512;  // most workgroups a dW launch uses (sizes the slab workspace): two per CU for the direct
+                                // kernel, one per CU (LDS-bound) for the ring kernels
+constexpr int kDwRingBlocks = 256;
+constexpr bool kDwDirectDefault = false;
 
 template <int KP>
 constexpr int tile_nbuf() { return KP == 128 ? 2 : 4; }
@@ -1664,7 +1834,14 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     const int KP = padded_width(din), NP = padded_width(dout);
     hipStream_t s = (hipStream_t)stream;
     // small graphs: fewer persistent workgroups (>= 16 chunks each), and only their slabs are cleared / summed
-    const int nblocks = plan->n_units / 16 < 1 ? 1 : (plan->n_units / 16 > kDwBlocks ? kDwBlocks : plan->n_units / 16);
+    // RGCN_DW_DIRECT: 0 never, 1 where it pays (large walks), 2 always (tests); default kDwDirectDefault
+    const char* direct_s0 = getenv("RGCN_DW_DIRECT");
+    const int direct_mode = direct_s0 ? atoi(direct_s0) : (kDwDirectDefault ? 1 : 0);
+    const bool want_direct = padded_width(din) == 64 && padded_width(dout) == 64 &&
+                             buffer_bytes(plan->n_nodes, ldx) != 0 && buffer_bytes(plan->n_owned, ldg) != 0 &&
+                             (direct_mode == 2 || (direct_mode == 1 && plan->n_units >= 64 * 1024));
+    const int max_blocks = want_direct ? kDwBlocks : kDwRingBlocks;
+    const int nblocks = plan->n_units / 16 < 1 ? 1 : (plan->n_units / 16 > max_blocks ? max_blocks : plan->n_units / 16);
     const size_t slab_bytes = sizeof(float) * (size_t)(nblocks + plan->num_relations + 1) * kDwSlabsPer * KP * NP;
     float* bias_slabs = (float*)workspace + dw_slab_floats(plan->num_relations, KP, NP);
     hipError_t e = hipMemsetAsync(workspace, 0, slab_bytes, s);
@@ -1694,7 +1871,12 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.n_units = plan->n_units;
     a.ushift = plan->chunk == 128 ? 1 : 0;
     a.num_rel = plan->num_relations;
-    st = dispatch_dw(KP, NP, a, nblocks, s);
+    if (want_direct) {
+        hipLaunchKernelGGL(rgcn_dw_direct_kernel, dim3(nblocks), dim3(256), 0, s, a);
+        st = (int)hipGetLastError();
+    } else {
+        st = dispatch_dw(KP, NP, a, nblocks, s);
+    }
     if (st != RGCN_OK) return st;
     hipLaunchKernelGGL(rgcn_dw_reduce_kernel, dim3(plan->num_relations + 2, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs, a.bias_slabs,
                        plan->rel_order, plan->chunk_rel, plan->n_units, a.ushift, nblocks, plan->num_relations, KP, NP, din,

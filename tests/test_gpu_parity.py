@@ -169,6 +169,30 @@ def test_chunk128_plans(dev, din, dout, tile):
     # and bit-identical gradients of the weights to the 64-slot layout?  No: the walk differs; same tolerance only.
 
 
+@pytest.mark.parametrize("chunk", [64, 128])
+def test_dw_direct_kernel(dev, monkeypatch, chunk):
+    """The direct-gather dW kernel (64 x 64; normally chosen for large walks only) against the oracle and, bit for
+    bit in its root / bias parts' inputs, against the ring kernel on the same plan."""
+    monkeypatch.setenv("RGCN_DW_DIRECT", "2")
+    n, e, r, din, dout = 5000, 90000, 7, 64, 64
+    ei, et = O.synthetic_graph(n, e, r, seed=21)
+    ei[:, 50:90] = ei[:, 10:50]             # duplicate edges
+    w, root, bias = O.synthetic_params(r, din, dout, seed=6)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    out, dx, dw, dr, db = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=128, chunk=chunk)
+    c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
+    assert_close(dw, gr["weight"], c["weight"], "d_weight (direct)")
+    assert_close(dr, gr["root"], c["root"], "d_root (direct)")
+    assert_close(db, gr["bias"], c["bias"], "d_bias (direct)")
+    monkeypatch.setenv("RGCN_DW_DIRECT", "0")
+    _, _, dw0, dr0, db0 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=128, chunk=chunk)
+    assert_close(dw, dw0, c["weight"], "direct vs ring d_weight")
+    assert_close(db, db0, c["bias"], "direct vs ring d_bias")
+
+
 def test_skewed_hub_graph_and_sum_aggr(dev):
     n, e, r, din, dout = 4000, 60000, 5, 64, 64
     ei, et = O.synthetic_graph(n, e, r, seed=5, skew=True)
