@@ -1471,10 +1471,15 @@ __global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) 
 #pragma unroll
                     for (int ia = 0; ia < 4; ++ia)
 #pragma unroll
-                        for (int jb = 0; jb < 4; ++jb)
+                        for (int jb = 0; jb < 4; ++jb) {
+                            if (RGCN_ABL & 1) {   // diagnostic build: no MFMA (memory rate of the walk)
+                                if (jb == 0) acc[ia][0][0] += o.a4[s][ia] * bv[ia];
+                                continue;
+                            }
                             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
                                          : "+v"(acc[ia][jb])
                                          : "v"(o.a4[s][ia]), "v"(bv[jb]));
+                        }
                 }
                 if (is_root) {      // bias gradient: plain column sums of the root rows
 #pragma unroll
@@ -1582,7 +1587,7 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
 constexpr int kDwBlocks = 512;  // most workgroups a dW launch uses (sizes the slab workspace): two per CU for the direct
                                 // kernel, one per CU (LDS-bound) for the ring kernels
 constexpr int kDwRingBlocks = 256;
-constexpr bool kDwDirectDefault = false;
+constexpr bool kDwDirectDefault = true;
 
 template <int KP>
 constexpr int tile_nbuf() { return KP == 128 ? 2 : 4; }
