@@ -1541,36 +1541,40 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
                                       int n_chunks, int ushift, int nblocks, int num_rel, int KP, int NP, int din, int dout,
                                       float* __restrict__ d_weight, float* __restrict__ d_root,
                                       float* __restrict__ d_bias) {
-    const int r = blockIdx.x;
-    if (r == num_rel + 1) {
-        if (d_bias == nullptr || blockIdx.y != 0) return;
+    const bool is_bias = blockIdx.x == num_rel + 1;
+    const int r = is_bias ? num_rel : blockIdx.x;            // the bias gradient comes from the root relation's rows
+    if (is_bias && (d_bias == nullptr || blockIdx.y != 0)) return;
+    float* dst = is_bias ? d_bias : (r < num_rel ? (d_weight ? d_weight + (size_t)r * din * dout : nullptr) : d_root);
+    if (dst == nullptr) return;
+    // which workgroups' unit ranges touch relation r: all threads look (two dependent loads per workgroup -- as a serial
+    // scan by one thread this was 0.7 ms with 512 workgroups)
+    __shared__ int s_lo, s_hi;
+    if (threadIdx.x == 0) {
+        s_lo = nblocks;
+        s_hi = -1;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        const int i0 = (int)((long)b * n_chunks / nblocks);
+        const int i1 = (int)((long)(b + 1) * n_chunks / nblocks);
+        if (i1 <= i0) continue;
+        const int first = chunk_rel[rel_order[i0] >> ushift], last = chunk_rel[rel_order[i1 - 1] >> ushift];
+        if (r >= first && r <= last) {
+            atomicMin(&s_lo, b);
+            atomicMax(&s_hi, b);
+        }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    if (is_bias) {      // only the workgroups that walked root units wrote bias slabs (summing all 2048 was 0.7 ms)
         for (int n = threadIdx.x; n < dout; n += blockDim.x) {
             float s = 0.f;
-            for (int b = 0; b < nblocks * kDwSlabsPer; ++b) s += bias_slabs[(size_t)b * NP + n];
+            for (int b = lo; b <= hi; ++b)
+                for (int c = 0; c < kDwSlabsPer; ++c) s += bias_slabs[((size_t)b * kDwSlabsPer + c) * NP + n];
             d_bias[n] = s;
         }
         return;
     }
-    float* dst = r < num_rel ? (d_weight ? d_weight + (size_t)r * din * dout : nullptr) : d_root;
-    if (dst == nullptr) return;
-    __shared__ int s_lo, s_hi;
-    if (threadIdx.x == 0) {
-        int lo = nblocks, hi = -1;
-        for (int b = 0; b < nblocks; ++b) {
-            const int i0 = (int)((long)b * n_chunks / nblocks);
-            const int i1 = (int)((long)(b + 1) * n_chunks / nblocks);
-            if (i1 <= i0) continue;
-            const int first = chunk_rel[rel_order[i0] >> ushift], last = chunk_rel[rel_order[i1 - 1] >> ushift];
-            if (r >= first && r <= last) {
-                lo = b < lo ? b : lo;
-                hi = b;
-            }
-        }
-        s_lo = lo;
-        s_hi = hi;
-    }
-    __syncthreads();
-    const int lo = s_lo, hi = s_hi;
     for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < din * dout; e += gridDim.y * blockDim.x) {
         const int k = e / dout, n = e - k * dout;
         float s = 0.f;
