@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PMC_TRAFFIC_FILE = "r01g_pmc_traffic.json"   # newest committed PMC pass
+PMC_TRAFFIC_FILE = "r01h_pmc_traffic.json"   # newest committed PMC pass
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), 155 measured
 
 
