@@ -39,14 +39,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 #ifndef RGCN_ABL
 #define RGCN_ABL 0
 #endif
-#ifndef RGCN_SGB
-#define RGCN_SGB 0
-#endif
 #ifndef RGCN_PRIO
 #define RGCN_PRIO 3
-#endif
-#ifndef RGCN_NT_H
-#define RGCN_NT_H 0   // cache policy of the wide dW kernel's H-row gather (probe: 2 = nt)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -147,7 +141,7 @@ struct RowGather {
             }
             if constexpr (BUF) {
                 const unsigned off = __umul24((unsigned)idx[i], rb) + co;
-                dma16_buf<RGCN_NT_H>(rsrc, off, dst);
+                dma16_buf(rsrc, off, dst);
             } else {
                 const float* gp = (idx[i] < n_rows && co != 0xFFFFFFF0u)
                                       ? (const float*)((const char*)(base + (size_t)idx[i] * ld) + co) : g_zero16;
@@ -1592,6 +1586,7 @@ constexpr int kDwBlocks = 512;  // most workgroups a dW launch uses (sizes the s
                                 // kernel, one per CU (LDS-bound) for the ring kernels
 constexpr int kDwRingBlocks = 256;
 constexpr bool kDwDirectDefault = true;
+constexpr int kDwDirectMinUnits = 16 * 1024;   // >= 8 units per wave of 512 four-wave workgroups
 
 template <int KP>
 constexpr int tile_nbuf() { return KP == 128 ? 2 : 4; }
@@ -1848,7 +1843,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     const int direct_mode = direct_s0 ? atoi(direct_s0) : (kDwDirectDefault ? 1 : 0);
     const bool want_direct = padded_width(din) == 64 && padded_width(dout) == 64 &&
                              buffer_bytes(plan->n_nodes, ldx) != 0 && buffer_bytes(plan->n_owned, ldg) != 0 &&
-                             (direct_mode == 2 || (direct_mode == 1 && plan->n_units >= 64 * 1024));
+                             (direct_mode == 2 || (direct_mode == 1 && plan->n_units >= kDwDirectMinUnits));
     const int max_blocks = want_direct ? kDwBlocks : kDwRingBlocks;
     const int nblocks = plan->n_units / 16 < 1 ? 1 : (plan->n_units / 16 > max_blocks ? max_blocks : plan->n_units / 16);
     const size_t slab_bytes = sizeof(float) * (size_t)(nblocks + plan->num_relations + 1) * kDwSlabsPer * KP * NP;

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "gpurun_out", "librgcn_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 abl = os.environ.get("RGCN_ABL", "0")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRGCN_STAMPS", "-DRGCN_ABL=" + abl, "-DRGCN_SGB=" + os.environ.get("RGCN_SGB", "0"),
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRGCN_STAMPS", "-DRGCN_ABL=" + abl,
                 os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_kernels.hip"), "-o", so], check=True)
 from scaling_rgcn_training_amd import _lib
 _lib.LIB_PATH = so
@@ -42,7 +42,7 @@ if which == 'fwd':
     s = s[:fp.n_tiles]
 nch = s[:, 7]
 tot_c = s[:, 0:4].sum(1); tot_p = s[:, 4:7].sum(1)
-print("SGB", os.environ.get("RGCN_SGB", "0"), "ABL", abl, "tiles", len(s), "chunks/tile mean", nch.mean())
+print("ABL", abl, "tiles", len(s), "chunks/tile mean", nch.mean())
 names = ["cons scalar-loads", "cons compute", "cons B-wait", "cons barrier", "prod issue", "prod dma-wait", "prod barrier"]
 for i, nm in enumerate(names):
     print(f"{nm:20s} {s[:, i].sum() / nch.sum():9.1f} cycles/chunk")
