@@ -83,13 +83,17 @@ def check(status: int, what: str) -> None:
 
 def plan_struct(plan) -> RgcnPlanStruct:
     """Fill the C struct from a plan.TilePlan whose tensors live on the GPU."""
+    cached = getattr(plan, "_cstruct", None)       # the plan's tensors never change: build the struct once
+    if cached is not None:
+        return cached
     if plan.slot_src.device.type != "cuda":
         raise RgcnLibraryError("the graph plan must live on the GPU (plan tensors are on %s)" % plan.slot_src.device)
-    return RgcnPlanStruct(
+    plan._cstruct = RgcnPlanStruct(
         plan.n_nodes, plan.n_owned, plan.num_relations, plan.tile, plan.n_tiles, plan.n_chunks, plan.chunk, plan.n_units,
         plan.tile_ptr.data_ptr(), plan.chunk_rel.data_ptr(), plan.chunk_cnt.data_ptr(),
         plan.chunk_tile.data_ptr(), plan.chunk_flags.data_ptr(), plan.rel_order.data_ptr(), plan.slot_src.data_ptr(),
         plan.slot_w.data_ptr(), plan.slot_row.data_ptr(), plan.slot_acc.data_ptr())
+    return plan._cstruct
 
 
 def _stream() -> int:
