@@ -23,8 +23,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, dw_direct):
     sys.path.insert(0, ROOT)
+    os.environ["RGCN_DW_DIRECT"] = dw_direct       # 0: ring dW kernels, 2: the direct-gather kernel on every piece
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,11 +75,12 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_partitioned_layer_equals_single_rank():
+@pytest.mark.parametrize("dw_direct", ["0", "2"])
+def test_two_ranks_one_gpu_partitioned_layer_equals_single_rank(dw_direct):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, dw_direct)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
