@@ -169,12 +169,12 @@ def test_chunk128_plans(dev, din, dout, tile):
     # and bit-identical gradients of the weights to the 64-slot layout?  No: the walk differs; same tolerance only.
 
 
-@pytest.mark.parametrize("chunk", [64, 128])
-def test_dw_direct_kernel(dev, monkeypatch, chunk):
+@pytest.mark.parametrize("chunk,din,dout", [(64, 64, 64), (128, 64, 64), (128, 50, 33), (64, 63, 40)])
+def test_dw_direct_kernel(dev, monkeypatch, chunk, din, dout):
     """The direct-gather dW kernel (64 x 64; normally chosen for large walks only) against the oracle and, bit for
     bit in its root / bias parts' inputs, against the ring kernel on the same plan."""
     monkeypatch.setenv("RGCN_DW_DIRECT", "2")
-    n, e, r, din, dout = 5000, 90000, 7, 64, 64
+    n, e, r = 5000, 90000, 7
     ei, et = O.synthetic_graph(n, e, r, seed=21)
     ei[:, 50:90] = ei[:, 10:50]             # duplicate edges
     w, root, bias = O.synthetic_params(r, din, dout, seed=6)
