@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    import __graft_entry__ as ge
+    ge.build()          # before anything touches the GPU or the process group (hipcc is a child process)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -138,8 +140,6 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    import __graft_entry__ as ge
-    ge.build()
     from scaling_rgcn_training_amd import _lib, dist as rdist
     from scaling_rgcn_training_amd.conv import RGCNConv
 

@@ -34,9 +34,19 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 7
-#define RGCN_CHUNK 64 /* edge slots per chunk == rows of one LDS ring slot */
+#define RGCN_ABI_VERSION 8
+#define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
+#define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
+#define RGCN_DW_WALKERS 2048 /* waves that walk rel_order side by side (512 workgroups x 4): the interleave of rel_order */
+
+/* activation fused into rgcn_fwd's store (reference model/layers.py:22 F.relu, :24 activation = torch.sigmoid) */
+enum rgcn_act { RGCN_ACT_NONE = 0, RGCN_ACT_RELU = 1, RGCN_ACT_SIGMOID = 2 };
+
+/* per-call options (bit mask); 0 = let the library choose */
+#define RGCN_FLAG_POINTER_GATHER 1u /* address gathered rows with 64-bit pointers even where a buffer descriptor fits */
+#define RGCN_FLAG_DW_RING 2u        /* rgcn_bwd_dw: LDS-ring kernels whatever the size */
+#define RGCN_FLAG_DW_DIRECT 4u      /* rgcn_bwd_dw: direct-gather kernel whenever the widths allow (64 x 64) */
 
 enum rgcn_status {
     RGCN_OK = 0,
@@ -46,7 +56,9 @@ enum rgcn_status {
     RGCN_ERR_PLAN = -4,      /* inconsistent plan (sizes <= 0, tile not a multiple of 16, ...) */
     RGCN_ERR_LDS = -5,       /* plan tile too large for the 160 KiB LDS at these widths */
     RGCN_ERR_WORKSPACE = -6, /* workspace smaller than the *_workspace_bytes query */
-    RGCN_ERR_DEVICE = -7     /* current device is not gfx950 / no device */
+    RGCN_ERR_DEVICE = -7,    /* current device is not gfx950 / no device */
+    RGCN_ERR_ACT = -8,       /* unknown activation code */
+    RGCN_ERR_GRAPH = -9      /* rgcn_plan_build: an edge_index / edge_type value is out of range */
 };
 
 /* Graph plan in HBM, built once per graph (scaling_rgcn_training_amd/plan.py documents the layout;
@@ -96,18 +108,27 @@ int rgcn_pack_weights(const float* weight, const float* root, int num_relations,
                       int transpose, float* packed, void* stream);
 
 /* Forward of RGCNConv.forward (aggr mean/sum folded into the plan's edge weights):
- *   out[i, :] = bias + sum_{slots scattering into i} w_e * x[src_e, :] @ W_{rel_e}   (root = rel R')
+ *   out[i, :] = act(bias + sum_{slots scattering into i} w_e * x[src_e, :] @ W_{rel_e})   (root = rel R')
  * x: [plan->n_nodes, ldx]; out: [plan->n_owned, ldo]; packed_w from rgcn_pack_weights(transpose=0);
- * bias: [dout] or NULL.  Columns dout..roundup4(dout) of out are written as zeros. */
+ * bias: [dout] or NULL.  Columns dout..roundup4(dout) of out are written as zeros.
+ * act: RGCN_ACT_* applied in the tile store -- what model/layers.py:22 (F.relu) and :24 (activation) run as
+ * separate elementwise kernels over [N, out]. */
 int rgcn_fwd(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* packed_w,
-             const float* bias, float* out, int ldo, int dout, void* stream);
+             const float* bias, float* out, int ldo, int dout, int act, unsigned flags, void* stream);
 
 /* dX of the layer (autograd of index_select/scatter-mean/matmul in PyG's loop), atomics-free:
  *   dx[j, :] = sum_{edges j->i, r} w_e * g[i, :] @ W_r^T + g[j, :] @ root^T
  * `plan_t` is the TRANSPOSED plan (edges grouped by source); g: [plan_t->n_nodes, ldg] upstream
- * gradient; packed_wt from rgcn_pack_weights(transpose=1); dx: [plan_t->n_owned, lddx]. */
+ * gradient; packed_wt from rgcn_pack_weights(transpose=1); dx: [plan_t->n_owned, lddx].
+ * relu_of (NULL or [plan_t->n_owned, ldr], the rows of the layer INPUT that dx belongs to): when the input was
+ * produced by a ReLU (the previous layer's fused RGCN_ACT_RELU), dx is stored as dx * (relu_of > 0), i.e. the
+ * gradient w.r.t. the previous layer's pre-activation: autograd's relu backward never runs as a kernel. */
 int rgcn_bwd_dx(const rgcn_plan_t* plan_t, const float* g, int ldg, int dout, const float* packed_wt,
-                float* dx, int lddx, int din, void* stream);
+                float* dx, int lddx, int din, const float* relu_of, int ldr, unsigned flags, void* stream);
+
+/* dz = da * act'(a) for an output a = act(z) of rgcn_fwd: relu -> da * (a > 0), sigmoid -> da * a * (1 - a).
+ * a, da, dz: [rows, ld] (dz may alias da).  For layers whose consumer cannot fold the mask (rgcn_bwd_dx relu_of). */
+int rgcn_act_backward(const float* a, const float* da, float* dz, long rows, int ld, int act, void* stream);
 
 /* Weight gradients: d_weight[r] = H_r^T g, d_root = X^T g, d_bias = column sums of g, over the
  * plan's owned rows (g: [plan->n_owned, ldg] is the upstream gradient of those rows).
@@ -116,7 +137,7 @@ int rgcn_bwd_dx(const rgcn_plan_t* plan_t, const float* g, int ldg, int dout, co
 size_t rgcn_bwd_dw_workspace_bytes(const rgcn_plan_t* plan, int din, int dout);
 int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* g, int ldg,
                 int dout, void* workspace, size_t workspace_bytes, float* d_weight, float* d_root,
-                float* d_bias, void* stream);
+                float* d_bias, unsigned flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,12 +14,16 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
-    "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
+    "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_act_backward", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
 )
+
+# enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT = 1, 2, 4
 
 
 class RgcnPlanStruct(C.Structure):
@@ -62,13 +66,16 @@ def load() -> C.CDLL:
     lib.rgcn_pack_weights.restype = i32
     lib.rgcn_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.rgcn_fwd.restype = i32
-    lib.rgcn_fwd.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, vp, vp, i32, i32, vp]
+    u32 = C.c_uint
+    lib.rgcn_fwd.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, vp, vp, i32, i32, i32, u32, vp]
     lib.rgcn_bwd_dx.restype = i32
-    lib.rgcn_bwd_dx.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, vp, i32, i32, vp]
+    lib.rgcn_bwd_dx.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, vp, i32, i32, vp, i32, u32, vp]
+    lib.rgcn_act_backward.restype = i32
+    lib.rgcn_act_backward.argtypes = [vp, vp, vp, C.c_long, i32, i32, vp]
     lib.rgcn_bwd_dw_workspace_bytes.restype = sz
     lib.rgcn_bwd_dw_workspace_bytes.argtypes = [C.POINTER(RgcnPlanStruct), i32, i32]
     lib.rgcn_bwd_dw.restype = i32
-    lib.rgcn_bwd_dw.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, i32, i32, vp, sz, vp, vp, vp, vp]
+    lib.rgcn_bwd_dw.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, i32, i32, vp, sz, vp, vp, vp, u32, vp]
     if lib.rgcn_abi_version() != ABI_VERSION:
         raise RgcnLibraryError(f"ABI version mismatch: library {lib.rgcn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
@@ -96,8 +103,9 @@ def plan_struct(plan) -> RgcnPlanStruct:
     return plan._cstruct
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t: torch.Tensor) -> int:
+    """the current torch stream OF THE TENSOR'S DEVICE (launches go where the data lives, like every torch op)"""
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -108,7 +116,7 @@ def padded_width(w: int) -> int:
     return load().rgcn_padded_width(int(w))
 
 
-# ---- thin typed wrappers: device tensors in, device tensors out, current torch stream ------------
+# ---- thin typed wrappers: device tensors in, device tensors out, current torch stream of the tensors' device ----
 def pack_weights(weight: torch.Tensor, root: Optional[torch.Tensor], transpose: bool) -> torch.Tensor:
     lib = load()
     r, din, dout = weight.shape
@@ -116,29 +124,44 @@ def pack_weights(weight: torch.Tensor, root: Optional[torch.Tensor], transpose: 
     if n == 0:
         raise RgcnLibraryError(f"unsupported layer widths {din}->{dout} (1..128 per side)")
     packed = torch.empty(n, dtype=torch.float32, device=weight.device)
-    check(lib.rgcn_pack_weights(weight.data_ptr(), _ptr(root), r, din, dout, int(transpose),
-                                packed.data_ptr(), _stream()), "rgcn_pack_weights")
+    with torch.cuda.device(weight.device):
+        check(lib.rgcn_pack_weights(weight.data_ptr(), _ptr(root), r, din, dout, int(transpose),
+                                    packed.data_ptr(), _stream(weight)), "rgcn_pack_weights")
     return packed
 
 
 def fwd(ps: RgcnPlanStruct, x: torch.Tensor, din: int, packed: torch.Tensor,
-        bias: Optional[torch.Tensor], out: torch.Tensor, dout: int) -> None:
-    check(load().rgcn_fwd(C.byref(ps), x.data_ptr(), x.stride(0), din, packed.data_ptr(), _ptr(bias),
-                          out.data_ptr(), out.stride(0), dout, _stream()), "rgcn_fwd")
+        bias: Optional[torch.Tensor], out: torch.Tensor, dout: int, act: int = ACT_NONE, flags: int = 0) -> None:
+    with torch.cuda.device(x.device):
+        check(load().rgcn_fwd(C.byref(ps), x.data_ptr(), x.stride(0), din, packed.data_ptr(), _ptr(bias),
+                              out.data_ptr(), out.stride(0), dout, int(act), int(flags), _stream(x)), "rgcn_fwd")
 
 
 def bwd_dx(ps_t: RgcnPlanStruct, g: torch.Tensor, dout: int, packed_t: torch.Tensor,
-           dx: torch.Tensor, din: int) -> None:
-    check(load().rgcn_bwd_dx(C.byref(ps_t), g.data_ptr(), g.stride(0), dout, packed_t.data_ptr(),
-                             dx.data_ptr(), dx.stride(0), din, _stream()), "rgcn_bwd_dx")
+           dx: torch.Tensor, din: int, relu_of: Optional[torch.Tensor] = None, flags: int = 0) -> None:
+    with torch.cuda.device(g.device):
+        check(load().rgcn_bwd_dx(C.byref(ps_t), g.data_ptr(), g.stride(0), dout, packed_t.data_ptr(),
+                                 dx.data_ptr(), dx.stride(0), din, _ptr(relu_of),
+                                 0 if relu_of is None else relu_of.stride(0), int(flags), _stream(g)), "rgcn_bwd_dx")
+
+
+def act_backward(a: torch.Tensor, da: torch.Tensor, act: int) -> torch.Tensor:
+    """dz = da * act'(a), a = act(z) (both [rows, ld] with the same 16-byte-aligned stride)"""
+    assert a.stride(0) == da.stride(0) and a.stride(1) == 1 and da.stride(1) == 1 and a.stride(0) % 4 == 0
+    dz = torch.empty_strided(da.shape, da.stride(), dtype=torch.float32, device=da.device)
+    with torch.cuda.device(a.device):
+        check(load().rgcn_act_backward(a.data_ptr(), da.data_ptr(), dz.data_ptr(), a.shape[0], a.stride(0), int(act),
+                                       _stream(a)), "rgcn_act_backward")
+    return dz
 
 
 def bwd_dw(ps: RgcnPlanStruct, x: torch.Tensor, din: int, g: torch.Tensor, dout: int,
            d_weight: Optional[torch.Tensor], d_root: Optional[torch.Tensor],
-           d_bias: Optional[torch.Tensor]) -> None:
+           d_bias: Optional[torch.Tensor], flags: int = 0) -> None:
     lib = load()
     nbytes = lib.rgcn_bwd_dw_workspace_bytes(C.byref(ps), din, dout)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(lib.rgcn_bwd_dw(C.byref(ps), x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0), dout,
-                          ws.data_ptr(), nbytes, _ptr(d_weight), _ptr(d_root), _ptr(d_bias), _stream()),
-          "rgcn_bwd_dw")
+    with torch.cuda.device(x.device):
+        check(lib.rgcn_bwd_dw(C.byref(ps), x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0), dout,
+                              ws.data_ptr(), nbytes, _ptr(d_weight), _ptr(d_root), _ptr(d_bias), int(flags), _stream(x)),
+              "rgcn_bwd_dw")

@@ -12,6 +12,7 @@ There is no CPU path: CPU tensors (or a missing HIP library) raise.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -35,20 +36,23 @@ def _rows16(t: Tensor, width: int) -> Tensor:
     return t.contiguous()
 
 
+# experiment overrides of the (tile, chunk) layout: read ONCE at import, never on the forward path
+_ENV_TILE = int(os.environ["RGCN_TILE"]) if "RGCN_TILE" in os.environ else None
+_ENV_CHUNK = int(os.environ["RGCN_CHUNK"]) if "RGCN_CHUNK" in os.environ else None
+
+_ACT_CODES = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID}
+
+
 def layout_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0,
                num_relations: int = 1) -> Tuple[int, int]:
     """(output nodes per tile, edge slots per chunk) for a layer (plan.choose_layout): bounded by the LDS budget of
-    the wider side, tuned to the graph's density.  ``RGCN_TILE`` / ``RGCN_CHUNK`` override (experiments)."""
+    the wider side, tuned to the graph's density.  ``RGCN_TILE`` / ``RGCN_CHUNK`` in the environment at import time
+    override (experiments)."""
     if not (1 <= in_channels <= 128 and 1 <= out_channels <= 128):
         raise ValueError(f"RGCNConv widths must be in 1..128, got {in_channels}->{out_channels}")
-    import os
     from .plan import choose_layout
     tile, chunk = choose_layout(n_nodes, n_edges, num_relations, in_channels, out_channels)
-    if "RGCN_TILE" in os.environ:
-        tile = int(os.environ["RGCN_TILE"])
-    if "RGCN_CHUNK" in os.environ:
-        chunk = int(os.environ["RGCN_CHUNK"])
-    return tile, chunk
+    return (_ENV_TILE or tile), (_ENV_CHUNK or chunk)
 
 
 def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0, num_relations: int = 1) -> int:
@@ -60,11 +64,15 @@ class DistContext:
     """One process per GPU.  Output nodes are cut into ``pieces * world`` equal tile-aligned blocks, dealt
     piece-major: block (s, r) = rows [(s * world + r) * piece_rows, +piece_rows) belongs to rank r.  A rank
     computes piece s straight into its block of the gathered buffer and all-gathers the contiguous
-    super-block s asynchronously while it computes piece s + 1 (dist.py)."""
+    super-block s asynchronously while it computes piece s + 1 (dist.py).  ``stats`` counts what the collectives
+    moved (bench.py reports it per step)."""
 
     def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int):
         self.group, self.rank, self.world = group, rank, world
         self.piece_rows, self.pieces = piece_rows, pieces
+        self.stats = {"all_gather": 0, "all_gather_bytes": 0, "all_reduce": 0, "all_reduce_bytes": 0,
+                      "wait_events": []}
+        self.time_waits = False     # bench.py: HIP events around the waits on the collectives
 
     @property
     def total_rows(self) -> int:
@@ -76,14 +84,21 @@ class DistContext:
         return b, b + self.piece_rows
 
     def node_range(self, s: int, n_nodes: int, r: Optional[int] = None) -> Tuple[int, int]:
+        """owned node range of block (s, r), clipped to the graph; a block that lies wholly past the last node is
+        the empty range at the tile-aligned end (n_nodes rounded up would not be a valid begin otherwise)"""
         b, e = self.block(s, r)
-        return min(b, n_nodes), min(e, n_nodes)
+        if b >= n_nodes:
+            return b, b
+        return b, min(e, n_nodes)
 
 
-def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, device) -> Tensor:
+def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, device,
+                   dtype: torch.dtype = torch.float32) -> Tensor:
     """Run ``launch(plan, out_rows)`` for every piece this rank owns and all-gather the pieces, overlapping
-    the collective of piece s (RCCL's own stream) with the kernels of piece s + 1 (current stream)."""
-    full = torch.empty(dctx.total_rows, ld, dtype=torch.float32, device=device)
+    the collective of piece s (RCCL's own stream) with the kernels of piece s + 1 (current stream).  The
+    all-gather is IN PLACE: this rank's block is already where the collective would put it (sendbuf ==
+    recvbuf + rank * count, the aliasing NCCL / RCCL document for in-place all-gather)."""
+    full = torch.empty(dctx.total_rows, ld, dtype=dtype, device=device)
     handles = []
     w, pr = dctx.world, dctx.piece_rows
     for s_idx, plan in enumerate(plans_list):
@@ -91,20 +106,33 @@ def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, dev
         mine = full[b:b + pr]
         if plan.n_owned > 0:
             launch(plan, mine)
+        if plan.n_owned < pr:
+            mine[plan.n_owned:].zero_()     # rows past the graph's end: defined bytes on the wire
         sup = full[s_idx * w * pr:(s_idx + 1) * w * pr]
         handles.append(torch.distributed.all_gather_into_tensor(sup, mine, group=dctx.group, async_op=True))
-    for h in handles:
-        h.wait()
+        dctx.stats["all_gather"] += 1
+        dctx.stats["all_gather_bytes"] += (w - 1) * pr * ld * full.element_size()      # bytes this rank RECEIVES
+    if dctx.time_waits and device.type == "cuda":
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for h in handles:
+            h.wait()
+        e1.record()
+        dctx.stats["wait_events"].append((e0, e1))
+    else:
+        for h in handles:
+            h.wait()
     return full[:n]
 
 
 class _RGCNLayerFn(torch.autograd.Function):
-    """out = sum_r mean-aggregate_r(x) @ W_r + x @ root + bias   (forward: rgcn_fwd;
-    backward: rgcn_bwd_dx on the transposed plan + rgcn_bwd_dw)."""
+    """a = act(sum_r mean-aggregate_r(x) @ W_r + x @ root + bias)   (forward: rgcn_fwd with the activation fused
+    into its store; backward: rgcn_bwd_dx on the transposed plan + rgcn_bwd_dw)."""
 
     @staticmethod
     def forward(ctx, x: Tensor, w_full: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
-                plans: GraphPlans, dctx: Optional[DistContext]):
+                plans: GraphPlans, dctx: Optional[DistContext], act: int, input_relu: bool, grad_premasked: bool,
+                flags: int):
         n, din = x.shape
         num_rel, _, dout = w_full.shape
         fp: Optional[TilePlan] = plans.fwd if dctx is None else None
@@ -116,76 +144,91 @@ class _RGCNLayerFn(torch.autograd.Function):
         ldo = _round4(dout)
         if dctx is None:
             out = torch.empty(n, ldo, dtype=torch.float32, device=x.device)
-            _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, out, dout)
+            _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, out, dout, act, flags)
         else:
             # every rank computes its own blocks straight into the gathered buffer; with destination-range
             # ownership the per-layer all-reduce of SURVEY.md 8e degenerates to an all-gather (each row has
             # exactly one non-zero contributor), issued piece by piece under the next piece's kernels
             out = _gather_pieces(dctx, [p.fwd for p in plans.pieces],
-                                 lambda pl, rows: _lib.fwd(_lib.plan_struct(pl), xp, din, packed, bs, rows, dout),
+                                 lambda pl, rows: _lib.fwd(_lib.plan_struct(pl), xp, din, packed, bs, rows, dout, act, flags),
                                  ldo, n, x.device)
         ctx.plans, ctx.dctx = plans, dctx
         ctx.dims = (n, din, dout, num_rel)
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
-        ctx.save_for_backward(xp, wf, rt)
+        ctx.act, ctx.input_relu, ctx.flags = act, input_relu, flags
+        # the activated output is only needed to differentiate the activation; a ReLU whose consumer folds the mask
+        # into its dX store (grad_premasked) needs nothing
+        need_a = act == _lib.ACT_SIGMOID or (act == _lib.ACT_RELU and not grad_premasked)
+        ctx.need_a = need_a
+        ctx.save_for_backward(xp, wf, rt, out if need_a else None)
         return out if ldo == dout else out[:, :dout]
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        xp, wf, rt = ctx.saved_tensors
-        plans, dctx = ctx.plans, ctx.dctx
+        xp, wf, rt, a_out = ctx.saved_tensors
+        plans, dctx, flags = ctx.plans, ctx.dctx, ctx.flags
         n, din, dout, num_rel = ctx.dims
         need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
         gp = _rows16(g, dout)
+        if ctx.need_a:
+            gp = _lib.act_backward(a_out, gp, ctx.act)       # dL/dz = dL/da * act'(a)
         dx = dw = droot = dbias = None
         if need_x:
             packed_t = _lib.pack_weights(wf, rt, transpose=True)
             ldx = _round4(din)
+            mask = xp if ctx.input_relu else None            # x = relu(z_prev): store dL/dz_prev = dx * (x > 0)
             if dctx is None:
                 dxp = torch.empty(n, ldx, dtype=torch.float32, device=g.device)
-                _lib.bwd_dx(_lib.plan_struct(plans.bwd), gp, dout, packed_t, dxp, din)
+                _lib.bwd_dx(_lib.plan_struct(plans.bwd), gp, dout, packed_t, dxp, din, mask, flags)
             else:
-                dxp = _gather_pieces(dctx, [p.bwd for p in plans.pieces],
-                                     lambda pl, rows: _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din),
-                                     ldx, n, g.device)
+                dxp = _gather_pieces(
+                    dctx, [p.bwd for p in plans.pieces],
+                    lambda pl, rows: _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din,
+                                                 None if mask is None else mask[pl.node_begin:pl.node_end], flags),
+                    ldx, n, g.device)
             dx = dxp if ldx == din else dxp[:, :din]
         need_root = need_root and ctx.has_root
         need_bias = need_bias and ctx.has_bias
         if need_w or need_root or need_bias:
             dev = g.device
             fplans = [plans.fwd] if dctx is None else [p.fwd for p in plans.pieces]
+            sizes = [num_rel * din * dout if need_w else 0, din * dout if need_root else 0, dout if need_bias else 0]
+
+            def views(flat):
+                o0, o1 = sizes[0], sizes[0] + sizes[1]
+                return (flat[:o0].view(num_rel, din, dout) if need_w else None,
+                        flat[o0:o1].view(din, dout) if need_root else None,
+                        flat[o1:].view(dout) if need_bias else None)
+
+            # ONE flat buffer for the three gradients: a single all-reduce in the distributed case
             acc = None
             for fp in fplans:
                 if fp.n_owned <= 0:
                     continue
-                pw = torch.empty(num_rel, din, dout, dtype=torch.float32, device=dev) if need_w else None
-                pr = torch.empty(din, dout, dtype=torch.float32, device=dev) if need_root else None
-                pb = torch.empty(dout, dtype=torch.float32, device=dev) if need_bias else None
-                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb)
-                if acc is None:
-                    acc = [pw, pr, pb]
-                else:
-                    for t, u in zip(acc, (pw, pr, pb)):
-                        if t is not None:
-                            t.add_(u)
+                part = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+                pw, pr, pb = views(part)
+                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb, flags)
+                acc = part if acc is None else acc.add_(part)
             if acc is None:
-                acc = [torch.zeros(num_rel, din, dout, device=dev) if need_w else None,
-                       torch.zeros(din, dout, device=dev) if need_root else None,
-                       torch.zeros(dout, device=dev) if need_bias else None]
-            dw, droot, dbias = acc
+                acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
             if dctx is not None:
-                for t in (dw, droot, dbias):
-                    if t is not None:
-                        torch.distributed.all_reduce(t, group=dctx.group)
-        return dx, dw, droot, dbias, None, None
+                torch.distributed.all_reduce(acc, group=dctx.group)
+                dctx.stats["all_reduce"] += 1
+                dctx.stats["all_reduce_bytes"] += acc.numel() * 4
+            dw, droot, dbias = views(acc)
+        return dx, dw, droot, dbias, None, None, None, None, None, None
 
 
 def rgcn_conv_function(x: Tensor, w_full: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
-                       plans: GraphPlans, dctx: Optional[DistContext] = None) -> Tensor:
+                       plans: GraphPlans, dctx: Optional[DistContext] = None, activation: Optional[str] = None,
+                       input_relu: bool = False, grad_premasked: bool = False, flags: int = 0) -> Tensor:
     if x.device.type != "cuda":
         raise RuntimeError("RGCNConv runs only on an MI355X (ROCm 'cuda' device); there is no CPU fallback")
+    if activation not in _ACT_CODES:
+        raise ValueError(f"fused activation must be one of {list(_ACT_CODES)}")
     _lib.load()
-    return _RGCNLayerFn.apply(x, w_full, root, bias, plans, dctx)
+    return _RGCNLayerFn.apply(x, w_full, root, bias, plans, dctx, _ACT_CODES[activation], bool(input_relu),
+                              bool(grad_premasked), int(flags))
 
 
 def glorot_(t: Tensor) -> Tensor:
@@ -229,6 +272,7 @@ class RGCNConv(nn.Module):
         self.is_sorted = is_sorted  # only meaningful for PyG's pyg_lib path; plans are order-independent
         self.dist: Optional[DistContext] = None
         self._dist_plans = None
+        self.kernel_flags = 0     # RGCN_FLAG_* passed to every launch of this layer (tests pin kernel paths with it)
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
             self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
@@ -286,7 +330,14 @@ class RGCNConv(nn.Module):
         from .dist import cached_rank_plans
         return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk)
 
-    def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None, *,
+                _activation: Optional[str] = None, _input_relu: bool = False,
+                _grad_premasked: bool = False) -> Tensor:
+        """PyG's ``forward(x, edge_index, edge_type)``.  The keyword-only arguments are the private hook the model
+        wrappers use to fuse the activations either side of the layer (layers._RGCNStack._tail):
+        ``_activation`` ('relu' | 'sigmoid') is applied in the forward kernel's store; ``_input_relu`` says x is the
+        ReLU output of the previous layer, so the dX kernel stores dL/dz_prev = dX * (x > 0); ``_grad_premasked`` says
+        every consumer of THIS layer's ReLU output does that, so no ReLU backward runs here."""
         assert edge_type is not None, "edge_type is required (PyG RGCNConv asserts the same)"
         if x is None or not torch.is_floating_point(x):
             raise NotImplementedError("featureless (integer / None x) RGCNConv is never used by the reference "
@@ -294,7 +345,9 @@ class RGCNConv(nn.Module):
         if x.dim() != 2 or x.shape[1] != self.in_channels:
             raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
         plans = self._plans(x, edge_index, edge_type)
-        return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist)
+        return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist,
+                                  _activation, _input_relu, _grad_premasked and _activation == "relu",
+                                  self.kernel_flags)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, "

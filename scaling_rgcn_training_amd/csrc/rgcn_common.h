@@ -17,7 +17,7 @@ namespace rgcn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kChunk = 64;          // edge slots per chunk (== RGCN_CHUNK)
+constexpr int kChunk = 64;          // edge slots per unit of the dW walk and per ring slot of the dW kernels (== RGCN_UNIT)
 constexpr int kThreads = 512;       // 8 waves: 0-3 producers, 4-7 consumers
 constexpr int kProducerWaves = 4;
 constexpr int kLdsBytes = 160 * 1024;

@@ -11,7 +11,8 @@
 //   rgcn_dw_kernel        weight gradients: per relation, dB_rel += (w_e x[src_e])^T g[dst_e]
 //                         (relation-major walk; register accumulators; one partial slab per (workgroup, rel))
 //   rgcn_dw_reduce_kernel fixed-order sum of the slabs -> d_weight / d_root / d_bias
-#include <cstdlib>
+#include <atomic>
+#include <cstring>
 #include <type_traits>
 #include "rgcn_common.h"
 #include "../../include/rgcn_mi355x.h"
@@ -41,6 +42,13 @@ __device__ __forceinline__ unsigned long long stamp() {
 #endif
 #ifndef RGCN_PRIO
 #define RGCN_PRIO 3
+#endif
+// run-time ablations of the tile kernel (1 skip MFMA + accumulate, 2 skip DMA, 4 skip B loads): only in diagnostic
+// builds (-DRGCN_DEBUG_KNOBS, set through rgcn_debug_set_mode); the product library has no such switch
+#ifdef RGCN_DEBUG_KNOBS
+#define RGCN_DBG(a) ((a).dbg)
+#else
+#define RGCN_DBG(a) 0
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +248,10 @@ struct TileArgs {
     unsigned x_bytes;  // rows * ldx * 4 when buffer-descriptor gathers are possible, else 0
     int n_rows;        // rows of x (padding slots carry this index)
     int ldx, din4, dout, ldo, tile, n_owned;
-    int dbg;  // diagnostic ablations (RGCN_DEBUG_MODE env): 1 skip MFMA+accumulate, 2 skip DMA, 4 skip B loads
+    const float* mask;  // dX only: rows of the layer INPUT when that input is a ReLU output (dx *= mask > 0), or NULL
+    int ldm;
+    int act;            // forward only: RGCN_ACT_* applied in the tile store
+    int dbg;            // diagnostic builds only (RGCN_DBG)
 };
 
 // accumulator row stride of the tile kernel's LDS tile (floats)
@@ -350,7 +361,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             asm volatile("" ::"s"(cnt), "s"(rel_next));
 #endif
             STAMP(t1);
-            const bool swap_b = active && rel_next != rel_cur && !(a.dbg & 4);
+            const bool swap_b = active && rel_next != rel_cur && !(RGCN_DBG(a) & 4);
             // the asm prefetch must never be spilled before its wait (hipcc believes the value is there):
             // only used where the fragment sets fit the register file comfortably
             constexpr bool kAsmPrefetch = SL * KT <= 4;
@@ -366,7 +377,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
                     }
                 }
             }
-            const int nrt_all = (!active || (a.dbg & 1)) ? 0 : (cnt + 15) >> 4;
+            const int nrt_all = (!active || (RGCN_DBG(a) & 1)) ? 0 : (cnt + 15) >> 4;
             const int flags_all = flags_chunk;
             // A chunk without repeated destinations runs as ONE straight-line block over all its row tiles (up to
             // CH / 16); otherwise 64-row parts of up to four tiles, each on the path its own flags ask for.
@@ -677,7 +688,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
         const int pw = wave;
         int knext = pw;                                   // this wave's next chunk
         RowGather<KP, kRowRead, BUF> gather;
-        gather.init(lane, (a.dbg & 2) ? 0 : a.din4, a.ldx);
+        gather.init(lane, (RGCN_DBG(a) & 2) ? 0 : a.din4, a.ldx);
 #ifdef RGCN_STAMPS
         unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
 #endif
@@ -788,10 +799,41 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
     const int row0 = tile * a.tile;
     const int rows = min(a.tile, a.n_owned - row0);
     const int o4 = (a.dout + 3) >> 2;
+    // Fused epilogues (reference model/layers.py:22,24: F.relu / activation applied to the layer output): the
+    // activation costs nothing here, as a separate kernel it re-reads and re-writes [N, out].  In the dX launch of the
+    // NEXT layer the ReLU backward of this layer's output is the mask (input > 0) on the stored gradient rows.
+    // Padding columns (dout .. 4 * o4) stay zero: relu(0) = 0, and sigmoid is applied to real columns only.
+    const int act = a.act;
     for (int i = tid; i < rows * o4; i += kTileThreads) {
         const int r = i / o4, c4 = i - r * o4;
-        const f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
+        f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
+        if (act == RGCN_ACT_RELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : 0.f;
+        } else if (act == RGCN_ACT_SIGMOID) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (c4 * 4 + c < a.dout) ? 1.f / (1.f + expf(-v[c])) : 0.f;
+        }
+        if (a.mask != nullptr) {
+            const f32x4 m = *(const f32x4*)(a.mask + (size_t)(row0 + r) * a.ldm + c4 * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = m[c] > 0.f ? v[c] : 0.f;
+        }
         *(f32x4*)(a.out + (size_t)(row0 + r) * a.ldo + c4 * 4) = v;
+    }
+}
+
+// dz = da * act'(a) for an activation fused into rgcn_fwd's store (a = act(z)): relu -> (a > 0), sigmoid -> a (1 - a).
+// 16 bytes per lane, grid-stride.  Used where no consumer kernel can fold the mask (rgcn_bwd_dx's `relu_of`).
+__global__ void rgcn_act_backward_kernel(const float* __restrict__ av, const float* __restrict__ da, float* __restrict__ dz,
+                                         long rows, int ld4, int act) {
+    const long total = rows * ld4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 y = ((const f32x4*)av)[i];
+        f32x4 g = ((const f32x4*)da)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) g[c] = act == RGCN_ACT_RELU ? (y[c] > 0.f ? g[c] : 0.f) : g[c] * y[c] * (1.f - y[c]);
+        ((f32x4*)dz)[i] = g;
     }
 }
 
@@ -1585,7 +1627,6 @@ __global__ void rgcn_dw_reduce_kernel(const float* __restrict__ slabs, const flo
 constexpr int kDwBlocks = 512;  // most workgroups a dW launch uses (sizes the slab workspace): two per CU for the direct
                                 // kernel, one per CU (LDS-bound) for the ring kernels
 constexpr int kDwRingBlocks = 256;
-constexpr bool kDwDirectDefault = true;
 constexpr int kDwDirectMinUnits = 16 * 1024;   // >= 8 units per wave of 512 four-wave workgroups
 
 template <int KP>
@@ -1609,13 +1650,41 @@ static int check_plan(const rgcn_plan_t* p) {
 // bytes of a [rows, ld] fp32 matrix if it can be gathered through a buffer descriptor: 24-bit row index and
 // row size (v_mad_u32_u24), 32-bit offsets with the one-past-the-end padding row and the all-ones "beyond
 // the width" offset out of range; else 0 -> the kernels fall back to 64-bit pointers
-static unsigned buffer_bytes(int rows, int ld) {
-    // RGCN_FORCE_POINTER_GATHER=1: exercise the 64-bit pointer fallback on small inputs (tests)
-    const char* force = getenv("RGCN_FORCE_POINTER_GATHER");
-    if (force && force[0] == '1') return 0u;
+// (RGCN_FLAG_POINTER_GATHER asks for that fallback on any input: how the tests reach it on small graphs)
+static unsigned buffer_bytes(int rows, int ld, unsigned flags) {
+    if (flags & RGCN_FLAG_POINTER_GATHER) return 0u;
     const size_t bytes = (size_t)rows * ld * sizeof(float);
     const size_t with_pad_row = bytes + (size_t)ld * sizeof(float);
     return (rows < (1 << 24) && with_pad_row < 0xFFFFFF00ull) ? (unsigned)bytes : 0u;
+}
+
+// The library is gfx950 code only: any other device (or none) is RGCN_ERR_DEVICE.  Looked up once per device.
+static int check_device() {
+    static std::atomic<int> state[64];          // 0 unknown, 1 gfx950, 2 other
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return RGCN_ERR_DEVICE;
+    if (dev >= 64) return RGCN_ERR_DEVICE;
+    int st = state[dev].load(std::memory_order_relaxed);
+    if (st == 0) {
+        hipDeviceProp_t prop;
+        st = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 2;
+        state[dev].store(st, std::memory_order_relaxed);
+    }
+    return st == 1 ? RGCN_OK : RGCN_ERR_DEVICE;
+}
+
+// Opt a kernel instantiation into the full 160 KiB of dynamic LDS: once per (instantiation, device), not per launch.
+template <auto KERN>
+static hipError_t allow_full_lds() {
+    static std::atomic<unsigned long long> done{0};     // one per kernel instantiation (KERN is a template argument)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 static int check_stride(int ld, int width) {
@@ -1626,9 +1695,10 @@ static int check_stride(int ld, int width) {
 
 template <int KP, int NP, int NBUF, int CH>
 static int launch_tile_nbuf(const TileArgs& a, int n_tiles, size_t lds, hipStream_t stream) {
-    auto kern = a.x_bytes ? rgcn_tile_kernel<KP, NP, NBUF, true, CH> : rgcn_tile_kernel<KP, NP, NBUF, false, CH>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = a.x_bytes ? allow_full_lds<rgcn_tile_kernel<KP, NP, NBUF, true, CH>>()
+                             : allow_full_lds<rgcn_tile_kernel<KP, NP, NBUF, false, CH>>();
     if (e != hipSuccess) return (int)e;
+    auto kern = a.x_bytes ? rgcn_tile_kernel<KP, NP, NBUF, true, CH> : rgcn_tile_kernel<KP, NP, NBUF, false, CH>;
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kTileThreads), lds, stream, a);
     return (int)hipGetLastError();
 }
@@ -1638,20 +1708,19 @@ static int launch_tile(const TileArgs& a, int n_tiles, int chunk, hipStream_t st
     auto bytes = [&](int nbuf) {
         return sizeof(float) * ((size_t)(a.tile + 1) * kAccStride<NP> + (size_t)nbuf * chunk * (KP + 2));
     };
-    const char* cap_s = getenv("RGCN_LDS_KB");     // experiment knob: LDS budget per workgroup
-    const size_t cap = cap_s ? (size_t)atoi(cap_s) * 1024 : (size_t)kLdsBytes;
+    constexpr size_t cap = (size_t)kLdsBytes;
     if (chunk == 128) {
         // 128-slot chunks: built for the widths whose ring slots leave room for a useful tile (KP <= 64)
         if constexpr (KP <= 64) {
             if (bytes(3) <= cap) return launch_tile_nbuf<KP, NP, 3, 128>(a, n_tiles, bytes(3), stream);
-            if (bytes(2) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 2, 128>(a, n_tiles, bytes(2), stream);
+            if (bytes(2) <= cap) return launch_tile_nbuf<KP, NP, 2, 128>(a, n_tiles, bytes(2), stream);
         }
         return RGCN_ERR_LDS;
     }
     if constexpr (kTileProducers >= 3)
         if (KP < 128 && bytes(4) <= cap) return launch_tile_nbuf<KP, NP, 4, 64>(a, n_tiles, bytes(4), stream);
     if (KP < 128 && bytes(3) <= cap) return launch_tile_nbuf<KP, NP, 3, 64>(a, n_tiles, bytes(3), stream);
-    if (bytes(2) <= (size_t)kLdsBytes) return launch_tile_nbuf<KP, NP, 2, 64>(a, n_tiles, bytes(2), stream);
+    if (bytes(2) <= cap) return launch_tile_nbuf<KP, NP, 2, 64>(a, n_tiles, bytes(2), stream);
     return RGCN_ERR_LDS;
 }
 template <int KP>
@@ -1675,14 +1744,21 @@ static int dispatch_tile(int KP, int NP, const TileArgs& a, int n_tiles, int chu
     return RGCN_ERR_WIDTH;
 }
 
+#ifdef RGCN_DEBUG_KNOBS
+static std::atomic<int> g_debug_mode{0};
+#endif
+
 // shared by rgcn_fwd and rgcn_bwd_dx: gather rows of `x` (width kin), scatter into `out` (width nout)
 static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, const float* packed, const float* bias,
-                    float* out, int ldo, int nout, void* stream) {
+                    float* out, int ldo, int nout, int act, const float* mask, int ldm, unsigned flags, void* stream) {
     int st = check_plan(plan);
     if (st != RGCN_OK) return st;
     if (!x || !packed || !out) return RGCN_ERR_NULL;
     if ((st = check_stride(ldx, kin)) != RGCN_OK) return st;
     if ((st = check_stride(ldo, nout)) != RGCN_OK) return st;
+    if (mask != nullptr && (st = check_stride(ldm, nout)) != RGCN_OK) return st;
+    if (act != RGCN_ACT_NONE && act != RGCN_ACT_RELU && act != RGCN_ACT_SIGMOID) return RGCN_ERR_ACT;
+    if ((st = check_device()) != RGCN_OK) return st;
     TileArgs a;
     a.tile_ptr = plan->tile_ptr;
     a.chunk_rel = plan->chunk_rel;
@@ -1696,15 +1772,21 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.bias = bias;
     a.out = out;
     a.ldx = ldx;
-    a.x_bytes = buffer_bytes(plan->n_nodes, ldx);
+    a.x_bytes = buffer_bytes(plan->n_nodes, ldx, flags);
     a.n_rows = plan->n_nodes;
     a.din4 = (kin + 3) / 4;
     a.dout = nout;
     a.ldo = ldo;
     a.tile = plan->tile;
     a.n_owned = plan->n_owned;
-    const char* dbg = getenv("RGCN_DEBUG_MODE");
-    a.dbg = dbg ? atoi(dbg) : 0;
+    a.mask = mask;
+    a.ldm = ldm;
+    a.act = act;
+#ifdef RGCN_DEBUG_KNOBS
+    a.dbg = g_debug_mode.load();
+#else
+    a.dbg = 0;
+#endif
     return dispatch_tile(padded_width(kin), padded_width(nout), a, plan->n_tiles, plan->chunk, (hipStream_t)stream);
 }
 
@@ -1714,18 +1796,21 @@ static int launch_dw(const DwArgs& a, int nblocks, hipStream_t stream) {
     constexpr bool kWide = KP % 64 == 0 && NP % 64 == 0 && KP * NP <= 64 * 128;
     const size_t lds = sizeof(float) * ((size_t)NBUF * kChunk * (KP + NP + 1) + (kWide ? 2 * (2 * NBUF - 1) * kChunk : 0));
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
-    void (*kern)(const DwArgs);
     int threads = kThreads;
+    hipError_t e;
+    void (*kern)(const DwArgs);
+    const bool buf = a.x_bytes && a.g_bytes;
     if constexpr (kWide) {
         // 64x64: accumulators take 64 registers, two consumer teams fit; wider: one team
         constexpr int CONS = KP * NP <= 64 * 64 ? kWideConsumers : 4;
         threads = 64 * (kProducerWaves + CONS);
-        kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_wide_kernel<KP, NP, NBUF, true, CONS>
-                                        : rgcn_dw_wide_kernel<KP, NP, NBUF, false, CONS>;
+        e = buf ? allow_full_lds<rgcn_dw_wide_kernel<KP, NP, NBUF, true, CONS>>()
+                : allow_full_lds<rgcn_dw_wide_kernel<KP, NP, NBUF, false, CONS>>();
+        kern = buf ? rgcn_dw_wide_kernel<KP, NP, NBUF, true, CONS> : rgcn_dw_wide_kernel<KP, NP, NBUF, false, CONS>;
     } else {
-        kern = (a.x_bytes && a.g_bytes) ? rgcn_dw_kernel<KP, NP, NBUF, true> : rgcn_dw_kernel<KP, NP, NBUF, false>;
+        e = buf ? allow_full_lds<rgcn_dw_kernel<KP, NP, NBUF, true>>() : allow_full_lds<rgcn_dw_kernel<KP, NP, NBUF, false>>();
+        kern = buf ? rgcn_dw_kernel<KP, NP, NBUF, true> : rgcn_dw_kernel<KP, NP, NBUF, false>;
     }
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(threads), lds, stream, a);
     return (int)hipGetLastError();
@@ -1770,6 +1855,9 @@ extern "C" int rgcn_debug_set_stamps(unsigned long long* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(rgcn::g_stamps), &p, sizeof(p));
 }
 #endif
+#ifdef RGCN_DEBUG_KNOBS
+extern "C" void rgcn_debug_set_mode(int mode) { rgcn::g_debug_mode.store(mode); }
+#endif
 
 extern "C" const char* rgcn_status_string(int status) {
     switch (status) {
@@ -1780,7 +1868,9 @@ extern "C" const char* rgcn_status_string(int status) {
         case RGCN_ERR_PLAN: return "inconsistent graph plan";
         case RGCN_ERR_LDS: return "plan tile too large for the 160 KiB LDS at these widths";
         case RGCN_ERR_WORKSPACE: return "workspace too small";
-        case RGCN_ERR_DEVICE: return "no gfx950 device";
+        case RGCN_ERR_DEVICE: return "current device is not gfx950 (MI355X)";
+        case RGCN_ERR_ACT: return "unknown activation code";
+        case RGCN_ERR_GRAPH: return "edge_index / edge_type value out of range";
     }
     if (status > 0) return hipGetErrorString((hipError_t)status);
     return "unknown status";
@@ -1809,13 +1899,24 @@ extern "C" int rgcn_pack_weights(const float* weight, const float* root, int num
 }
 
 extern "C" int rgcn_fwd(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* packed_w,
-                        const float* bias, float* out, int ldo, int dout, void* stream) {
-    return run_tile(plan, x, ldx, din, packed_w, bias, out, ldo, dout, stream);
+                        const float* bias, float* out, int ldo, int dout, int act, unsigned flags, void* stream) {
+    return run_tile(plan, x, ldx, din, packed_w, bias, out, ldo, dout, act, nullptr, 0, flags, stream);
 }
 
 extern "C" int rgcn_bwd_dx(const rgcn_plan_t* plan_t, const float* g, int ldg, int dout, const float* packed_wt,
-                           float* dx, int lddx, int din, void* stream) {
-    return run_tile(plan_t, g, ldg, dout, packed_wt, nullptr, dx, lddx, din, stream);
+                           float* dx, int lddx, int din, const float* relu_of, int ldr, unsigned flags, void* stream) {
+    return run_tile(plan_t, g, ldg, dout, packed_wt, nullptr, dx, lddx, din, RGCN_ACT_NONE, relu_of, ldr, flags, stream);
+}
+
+extern "C" int rgcn_act_backward(const float* a, const float* da, float* dz, long rows, int ld, int act, void* stream) {
+    if (!a || !da || !dz) return RGCN_ERR_NULL;
+    if (ld <= 0 || (ld % 4) != 0) return RGCN_ERR_STRIDE;
+    if (act != RGCN_ACT_RELU && act != RGCN_ACT_SIGMOID) return RGCN_ERR_ACT;
+    if (rows <= 0) return RGCN_OK;
+    const long total = rows * (ld / 4);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(rgcn_act_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, da, dz, rows, ld / 4, act);
+    return (int)hipGetLastError();
 }
 
 extern "C" size_t rgcn_bwd_dw_workspace_bytes(const rgcn_plan_t* plan, int din, int dout) {
@@ -1827,7 +1928,7 @@ extern "C" size_t rgcn_bwd_dw_workspace_bytes(const rgcn_plan_t* plan, int din, 
 
 extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* g, int ldg,
                            int dout, void* workspace, size_t workspace_bytes, float* d_weight, float* d_root,
-                           float* d_bias, void* stream) {
+                           float* d_bias, unsigned flags, void* stream) {
     int st = check_plan(plan);
     if (st != RGCN_OK) return st;
     if (!x || !g || !workspace) return RGCN_ERR_NULL;
@@ -1835,15 +1936,16 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     if ((st = check_stride(ldg, dout)) != RGCN_OK) return st;
     const size_t need = rgcn_bwd_dw_workspace_bytes(plan, din, dout);
     if (workspace_bytes < need) return RGCN_ERR_WORKSPACE;
+    if ((st = check_device()) != RGCN_OK) return st;
     const int KP = padded_width(din), NP = padded_width(dout);
     hipStream_t s = (hipStream_t)stream;
-    // small graphs: fewer persistent workgroups (>= 16 chunks each), and only their slabs are cleared / summed
-    // RGCN_DW_DIRECT: 0 never, 1 where it pays (large walks), 2 always (tests); default kDwDirectDefault
-    const char* direct_s0 = getenv("RGCN_DW_DIRECT");
-    const int direct_mode = direct_s0 ? atoi(direct_s0) : (kDwDirectDefault ? 1 : 0);
-    const bool want_direct = padded_width(din) == 64 && padded_width(dout) == 64 &&
-                             buffer_bytes(plan->n_nodes, ldx) != 0 && buffer_bytes(plan->n_owned, ldg) != 0 &&
-                             (direct_mode == 2 || (direct_mode == 1 && plan->n_units >= kDwDirectMinUnits));
+    // The direct-gather kernel (64 x 64, buffer-addressable operands) pays on large walks; small graphs take fewer
+    // persistent workgroups (>= 16 units each) of the ring kernels, and only their slabs are cleared / summed.
+    // RGCN_FLAG_DW_RING / RGCN_FLAG_DW_DIRECT pin the choice (tests exercise both on small graphs).
+    const unsigned xb = buffer_bytes(plan->n_nodes, ldx, flags), gb = buffer_bytes(plan->n_owned, ldg, flags);
+    const bool can_direct = KP == 64 && NP == 64 && xb != 0 && gb != 0;
+    const bool want_direct = can_direct && !(flags & RGCN_FLAG_DW_RING) &&
+                             ((flags & RGCN_FLAG_DW_DIRECT) || plan->n_units >= kDwDirectMinUnits);
     const int max_blocks = want_direct ? kDwBlocks : kDwRingBlocks;
     const int nblocks = plan->n_units / 16 < 1 ? 1 : (plan->n_units / 16 > max_blocks ? max_blocks : plan->n_units / 16);
     const size_t slab_bytes = sizeof(float) * (size_t)(nblocks + plan->num_relations + 1) * kDwSlabsPer * KP * NP;
@@ -1864,8 +1966,8 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.slabs = (float*)workspace;
     a.bias_slabs = bias_slabs;
     a.ldx = ldx;
-    a.x_bytes = buffer_bytes(plan->n_nodes, ldx);
-    a.g_bytes = buffer_bytes(plan->n_owned, ldg);
+    a.x_bytes = xb;
+    a.g_bytes = gb;
     a.n_rows = plan->n_nodes;
     a.n_owned = plan->n_owned;
     a.din4 = (din + 3) / 4;

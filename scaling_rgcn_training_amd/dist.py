@@ -22,7 +22,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from .conv import DistContext, RGCNConv
-from .plan import GraphPlans, build_graph_plans, cached_graph_plans
+from .plan import GraphPlans, build_plan, cached_graph_plans, edge_weights
 
 
 PIECES = 4  # all-gather pipeline depth: the collective of piece s runs under the kernels of piece s + 1
@@ -54,11 +54,27 @@ class RankPlans:
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
                aggr: str, dctx: DistContext, chunk: int = 64) -> RankPlans:
+    """Plans of this rank's blocks.  The mean normaliser (a sort of all E keys) is computed ONCE, the edge list is
+    cut down to this rank's share ONCE per direction, and every piece is laid out from that share."""
+    src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+    rel = edge_type.to(torch.int64)
+    w = edge_weights(src, dst, rel, num_relations, aggr)
+    pr, world, rank = dctx.piece_rows, dctx.world, dctx.rank
+
+    def share(scatter, gather):
+        blk = scatter // pr
+        mine = (blk % world) == rank
+        return gather[mine], scatter[mine], rel[mine], w[mine], blk[mine] // world
+
+    fg, fs, fr, fw, fpiece = share(dst, src)       # forward: edges INTO my blocks
+    bg, bs, br, bw, bpiece = share(src, dst)       # transposed: edges OUT OF my blocks
     out = []
     for s in range(dctx.pieces):
         b, e = dctx.node_range(s, n_nodes)
-        out.append(build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr,
-                                     fwd_range=(b, e), bwd_range=(b, e), chunk=chunk))
+        fm, bm = fpiece == s, bpiece == s
+        fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk)
+        bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk)
+        out.append(GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(fm.sum())))
     return RankPlans(out)
 
 

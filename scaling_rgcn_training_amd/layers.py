@@ -24,6 +24,8 @@ class _RGCNStack(nn.Module):
     """x -> rgcn1 -> relu -> rgcn2 -> activation, the tail all three reference models share
     (model/layers.py:21-25, 62-66, 108-112), plus the parameter re-binding contract."""
 
+    fuse_activations = True   # False: F.relu / activation as separate torch kernels, exactly as the reference writes it
+
     def _build_convs(self, emb_dim: int, hidden_l: int, num_labels: int, num_relations: int) -> None:
         self.rgcn1 = RGCNConv(in_channels=emb_dim, out_channels=hidden_l, num_relations=num_relations, num_bases=None)
         self.rgcn2 = RGCNConv(hidden_l, num_labels, num_relations, num_bases=None)
@@ -33,8 +35,17 @@ class _RGCNStack(nn.Module):
         nn.init.kaiming_uniform_(self.rgcn2.weight, mode="fan_in")
 
     def _tail(self, x: Tensor, training_data: Data, activation: Callable) -> Tensor:
-        h = F.relu(self.rgcn1(x, training_data.edge_index, training_data.edge_type))
-        return activation(self.rgcn2(h, training_data.edge_index, training_data.edge_type))
+        """``activation(rgcn2(relu(rgcn1(x))))`` with both activations fused into the layer kernels: the ReLU in
+        rgcn1's store and -- because ``h`` is consumed by rgcn2 alone -- its backward as the mask on rgcn2's dX
+        store; ``torch.sigmoid`` in rgcn2's store.  Any other ``activation`` callable runs as given."""
+        ei, et = training_data.edge_index, training_data.edge_type
+        if not self.fuse_activations:
+            h = F.relu(self.rgcn1(x, ei, et))
+            return activation(self.rgcn2(h, ei, et))
+        h = self.rgcn1(x, ei, et, _activation="relu", _grad_premasked=True)
+        if activation is torch.sigmoid:
+            return self.rgcn2(h, ei, et, _activation="sigmoid", _input_relu=True)
+        return activation(self.rgcn2(h, ei, et, _input_relu=True))
 
     def override_params(self, weight_1: Tensor, bias_1: Tensor, root_1: Tensor, weight_2: Tensor,
                         bias_2: Tensor, root_2: Tensor, grad: bool = True) -> None:

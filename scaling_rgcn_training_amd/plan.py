@@ -201,12 +201,45 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     chunk_order = torch.sort(order_key, stable=True)[1]
     units = (chunk_order[:, None] * upc + torch.arange(upc, device=dev)[None, :]).reshape(-1)
     used = (chunk_cnt.to(torch.int64)[chunk_order][:, None] > UNIT * torch.arange(upc, device=dev)[None, :]).reshape(-1)
-    rel_order = units[used].to(torch.int32)
+    rel_order = interleave_walk(units[used], chunk_rel.to(torch.int64)[chunk_order].repeat_interleave(upc)[used],
+                                r1).to(torch.int32)
     return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end,
                     num_relations=num_relations, tile=tile, chunk=CHUNK, n_tiles=n_tiles, n_chunks=n_chunks,
                     n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
                     slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags)
+
+
+DW_WALKERS = 2048   # waves that walk rel_order side by side in the largest dW launch (512 workgroups x 4 waves)
+
+
+def interleave_walk(units: Tensor, unit_rel: Tensor, r1: int, walkers: int = DW_WALKERS) -> Tensor:
+    """Order of the weight-gradient walk.  ``units`` arrive sorted by (relation, tile).  A dW launch hands every wave
+    one CONTIGUOUS range of the walk (few relation changes = few accumulator flushes), so with the plain sorted
+    order the ~``walkers`` concurrent waves sit at ``walkers`` different tiles and every upstream-gradient row a slot
+    gathers comes from HBM: E * 4 * out bytes per launch although only N rows exist (55 GB instead of 29 GB at the
+    headline config, profiles/r01h_pmc_traffic.json).  Here the units of relation r (U_r of them, rank q by tile) are
+    dealt ROUND-ROBIN over J_r = round(U_r * walkers / n_units) pieces of consecutive positions -- piece q mod J_r,
+    place q div J_r -- so every piece sweeps the whole tile sequence and all pieces (of all relations) pass the same
+    tiles at the same time: a gradient row is fetched from HBM once and served to the other ~R' relations' waves from
+    L2 / the Infinity Cache.  Relations stay contiguous and ascending (what the slab reduction relies on); any order
+    inside a relation gives the same sums up to fp32 re-association.  Pure integer arithmetic, restated by the HIP
+    plan builder (csrc/rgcn_plan.hip)."""
+    n = int(units.shape[0])
+    if n == 0:
+        return units
+    dev = units.device
+    cnt = torch.bincount(unit_rel, minlength=r1)                       # U_r
+    start = torch.cumsum(cnt, 0) - cnt                                  # A_r
+    pieces = torch.clamp((cnt * walkers + n // 2) // n, min=1)          # J_r
+    q = torch.arange(n, device=dev) - start[unit_rel]
+    jr, ur = pieces[unit_rel], cnt[unit_rel]
+    j = q % jr
+    base, rem = ur // jr, ur % jr                                       # the first `rem` pieces hold base + 1 units
+    pos = start[unit_rel] + j * base + torch.minimum(j, rem) + q // jr
+    out = torch.empty_like(units)
+    out[pos] = units
+    return out
 
 
 ROWS_PER_MFMA_TILE = 16
@@ -217,42 +250,6 @@ ACC_PAD = 4    # floats of padding per accumulator row in the tile kernel's LDS 
 def padded_width(w: int) -> int:
     """the kernels pad feature widths to 16 / 32 / 64 / 128 (csrc/rgcn_common.h padded_width)"""
     return 16 if w <= 16 else 32 if w <= 32 else 64 if w <= 64 else 128
-
-
-def choose_tile(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int,
-                min_ring: int = 3) -> int:
-    """Output nodes per tile for a layer.  Both directions share the tile (forward: accumulator width =
-    out, dX: = in), so it is bounded by the wider side: (tile + 1) * (pad(width) + 4) * 4 B of accumulator plus
-    ``min_ring`` DMA ring slots of 64 * (pad(other width) + 2) * 4 B must fit the 160 KiB LDS.
-    Within that bound the tile is picked so that the expected (tile, relation) group -- tile * E / (N * R')
-    edges, roughly Poisson -- fills its 64-slot chunks best: every chunk costs a workgroup barrier and a
-    pipeline fill/drain whatever its fill (T = 384 instead of 256 was worth 13 % on the 10M-node graph)."""
-    import math
-    kp, np_ = padded_width(in_channels), padded_width(out_channels)
-
-    def fits(t):
-        fwd = (t + 1) * (np_ + ACC_PAD) * 4 + min_ring * CHUNK * (kp + 2) * 4
-        bwd = (t + 1) * (kp + ACC_PAD) * 4 + min_ring * CHUNK * (np_ + 2) * 4
-        return max(fwd, bwd) <= LDS_BYTES
-
-    cands = [t for t in range(64, 513, 32) if fits(t)] or [64]
-    # small graphs: parallelism before chunk fill -- one workgroup walks one tile, so keep >= 512 tiles (two
-    # per CU) as long as the tile does not drop below 64 nodes (AIFB-sized layers went 1.4 -> 0.8 ms)
-    few = [t for t in cands if n_nodes // t >= 512]
-    cands = few or cands[:1]
-    density = n_edges / max(1.0, float(n_nodes) * max(1, num_relations))
-
-    def fill(t):
-        g = density * t
-        if g <= 0:
-            return 0.0
-        sd = math.sqrt(g)
-        # E[ceil(X / 64)] for X ~ N(g, sd): sum_k P(X > 64 k)
-        chunks = sum(0.5 * math.erfc((CHUNK * k - g) / (sd * math.sqrt(2.0))) for k in range(0, int(g / CHUNK) + 6))
-        return g / (CHUNK * max(chunks, 1.0))
-
-    best = max(cands, key=lambda t: (round(fill(t), 2), t))  # ties -> the larger tile (fewer B-fragment reloads)
-    return best
 
 
 def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int):

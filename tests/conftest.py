@@ -34,3 +34,16 @@ def _fresh_library():
     run never exercises a stale binary."""
     import __graft_entry__ as g
     g.build()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How much of the slack over a flat 1e-5 / 1e-5 the parity checks used (oracle/tolerance.py bound (2))."""
+    from oracle.tolerance import SLACK_LOG
+    if not SLACK_LOG:
+        return
+    over = sorted((e for e in SLACK_LOG if e[1] > 0), key=lambda e: -e[1])
+    tr = terminalreporter
+    tr.write_line(f"parity: {len(SLACK_LOG)} tensor checks, {len(over)} used slack over flat 1e-5 + 1e-5|ref|")
+    for what, excess, cpu_err in over[:12]:
+        c = "n/a" if cpu_err is None else f"{cpu_err:.2e}"
+        tr.write_line(f"   {what:40s} worst excess over flat {excess:.2e}   fp32 CPU loop's own worst error {c}")

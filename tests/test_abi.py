@@ -40,7 +40,10 @@ def test_abi_version_and_sizes():
 def test_argument_errors_are_status_codes_not_crashes():
     lib = _lib.load()
     ps = _lib.RgcnPlanStruct()  # all zero / NULL
-    assert lib.rgcn_fwd(ctypes.byref(ps), None, 64, 64, None, None, None, 64, 64, None) == -1  # RGCN_ERR_NULL
+    assert lib.rgcn_fwd(ctypes.byref(ps), None, 64, 64, None, None, None, 64, 64, 0, 0, None) == -1  # RGCN_ERR_NULL
+    assert lib.rgcn_bwd_dx(ctypes.byref(ps), None, 64, 64, None, None, 64, 64, None, 0, 0, None) == -1
+    assert lib.rgcn_act_backward(None, None, None, 4, 8, 1, None) == -1
+    assert b"gfx950" in lib.rgcn_status_string(-7) and b"activation" in lib.rgcn_status_string(-8)
     assert lib.rgcn_pack_weights(None, None, 3, 8, 8, 0, None, None) == -1
     assert lib.rgcn_bwd_dw_workspace_bytes(None, 8, 8) == 0
 

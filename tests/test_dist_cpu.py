@@ -21,43 +21,38 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, n, e, tile, pieces):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import rgcn_oracle as O
     from scaling_rgcn_training_amd import dist as rdist, plan as P
+    from scaling_rgcn_training_amd.conv import _gather_pieces
     from tests.plan_emulator import emulate_dw, emulate_spmm
-    n, e, r, din, dout, tile = 1000, 9000, 5, 8, 6, 64
+    r, din, dout = 5, 8, 6
     ei, et = O.synthetic_graph(n, e, r, seed=4)
     w, root, bias = O.synthetic_params(r, din, dout, seed=4)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(n, din, generator=g).double()
     dg = torch.randn(n, dout, generator=g).double()
     w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0).astype(np.float64)
-    ctx = rdist.make_context(n, tile, pieces=3)
-    assert ctx is not None and ctx.world == world and ctx.rank == rank and ctx.pieces == 3
+    ctx = rdist.make_context(n, tile, pieces=pieces)
+    assert ctx is not None and ctx.world == world and ctx.rank == rank
     plans = rdist.rank_plans(ei, et, n, r, tile, "mean", ctx)
-    pr, tot = ctx.piece_rows, ctx.total_rows
+    assert len(plans.pieces) == ctx.pieces
+    assert sum(p.fwd.n_edges for p in plans.pieces) <= e
 
     def gather(plan_list, feat, w_mats, b_vec, width):
-        """conv._gather_pieces with the numpy plan walk as the kernel: own block -> async all-gather of its super-block"""
-        full = torch.zeros(tot, width, dtype=torch.float64)
-        handles = []
-        for s_idx, pl in enumerate(plan_list):
-            b, _ = ctx.block(s_idx)
-            mine = full[b:b + pr]
-            if pl.n_owned:
-                mine[:pl.n_owned] = torch.from_numpy(emulate_spmm(pl, feat, w_mats, b_vec))
-            sup = full[s_idx * world * pr:(s_idx + 1) * world * pr]
-            handles.append(dist.all_gather_into_tensor(sup, mine.clone(), async_op=True))
-        for h in handles:
-            h.wait()
-        return full[:n]
+        """the PRODUCT's pipeline (conv._gather_pieces: own block written in place, asynchronous in-place all-gather
+        of its super-block) with the numpy plan walk standing in for the kernel launch"""
+        def launch(pl, rows):
+            rows[:pl.n_owned] = torch.from_numpy(emulate_spmm(pl, feat, w_mats, b_vec))
+        return _gather_pieces(ctx, plan_list, launch, width, n, torch.device("cpu"), dtype=torch.float64)
 
     out = gather([p.fwd for p in plans.pieces], x.numpy(), w_all, bias.numpy(), dout)
     dx = gather([p.bwd for p in plans.pieces], dg.numpy(), np.transpose(w_all, (0, 2, 1)), None, din)
+    assert ctx.stats["all_gather"] == 2 * ctx.pieces
     # weight gradients: partial over the own blocks, all-reduced
     dw = torch.zeros(r + 1, din, dout, dtype=torch.float64)
     for p in plans.pieces:
@@ -80,14 +75,25 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_partition_matches_single_rank():
+def _run(world, n, e, tile, pieces):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, n, e, tile, pieces)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert ret.get(timeout=5) == "ok"
+
+
+def test_two_rank_gloo_partition_matches_single_rank():
+    _run(2, 1000, 9000, 64, 3)
+
+
+def test_two_rank_gloo_empty_trailing_blocks():
+    """n_nodes not a tile multiple and fewer tiles than world * pieces blocks can hold: 637 nodes / tile 64 = 10 tiles
+    in 2 x 4 blocks of 2 tiles -> blocks 5..7 lie (partly or wholly) past the last node (the case that raised
+    'node_begin must be a multiple of the tile size' in round 1)."""
+    _run(2, 637, 5000, 64, 4)

@@ -90,13 +90,15 @@ def test_rank_blocks_tile_aligned_and_cover():
         assert np.all(seen == 1)                     # every node owned by exactly one (rank, piece)
 
 
-def test_choose_tile_respects_lds_and_prefers_full_chunks():
-    from scaling_rgcn_training_amd.plan import CHUNK, LDS_BYTES, choose_tile, padded_width
+def test_choose_layout_respects_lds_and_amortises_chunks():
+    """plan.choose_layout is what the product uses (conv.layout_for): both directions of the layer must fit the
+    160 KiB LDS with at least two ring slots, and the headline graph gets 128-slot chunks on 352-node tiles."""
+    from scaling_rgcn_training_amd.plan import ACC_PAD, CHUNKS, LDS_BYTES, choose_layout, padded_width
     for args in ((10_000_000, 100_000_000, 32, 64, 64), (8243, 49838, 89, 63, 16), (1000, 9000, 5, 128, 128),
-                 (100, 0, 3, 8, 8), (5000, 10 ** 6, 2, 64, 128)):
-        t = choose_tile(*args)
+                 (100, 0, 3, 8, 8), (5000, 10 ** 6, 2, 64, 128), (23644, 150000, 45, 63, 16), (1_500_000, 6_000_000, 267, 32, 32)):
+        t, c = choose_layout(*args)
         kp, np_ = padded_width(args[3]), padded_width(args[4])
-        assert t % 16 == 0 and t >= 64
-        assert (t + 1) * max(kp, np_) * 4 + 2 * CHUNK * (min(kp, np_) + 2) * 4 <= LDS_BYTES
-    # the headline graph: 0.3125 edges per (node, relation); 384 nodes -> groups of ~120 = two nearly full chunks
-    assert choose_tile(10_000_000, 100_000_000, 32, 64, 64) == 384
+        assert t % 16 == 0 and t >= 64 and c in CHUNKS
+        for acc_w, ring_w in ((np_, kp), (kp, np_)):        # forward, dX
+            assert (t + 1) * (acc_w + ACC_PAD) * 4 + 2 * c * (ring_w + 2) * 4 <= LDS_BYTES
+    assert choose_layout(10_000_000, 100_000_000, 32, 64, 64) == (352, 128)

@@ -221,3 +221,30 @@ def test_plan_walk_random_graphs_property():
         np.testing.assert_allclose(dw[-1], grads["root"], rtol=2e-6, atol=2e-6)
 
     run()
+
+
+def test_dw_walk_interleave():
+    """rel_order: relations contiguous and ascending, every unit once, and inside a relation the units are dealt
+    round-robin over J_r pieces so that every piece sweeps the tile sequence (plan.interleave_walk)."""
+    from scaling_rgcn_training_amd.plan import interleave_walk
+    r1 = 6
+    cnt = torch.tensor([1000, 3, 0, 517, 2000, 1])
+    rel = torch.repeat_interleave(torch.arange(r1), cnt)
+    units = torch.arange(rel.numel())                  # unit id == rank in the (relation, tile) order
+    walkers = 64
+    out = interleave_walk(units, rel, r1, walkers=walkers)
+    assert sorted(out.tolist()) == units.tolist()
+    assert torch.all(rel[out][1:] >= rel[out][:-1])
+    n = int(rel.numel())
+    start = torch.cumsum(cnt, 0) - cnt
+    for r in range(r1):
+        u = int(cnt[r])
+        if u == 0:
+            continue
+        j_r = max(1, (u * walkers + n // 2) // n)
+        seg = (out[int(start[r]):int(start[r]) + u] - int(start[r])).tolist()      # ranks q in walk order
+        # piece j holds q = j, j + J, j + 2J, ... ascending; pieces follow each other
+        want = [q for j in range(j_r) for q in range(j, u, j_r)]
+        assert seg == want
+    # few walkers or few units: identity
+    assert torch.equal(interleave_walk(units[:40], rel[:40], r1, walkers=2048), units[:40])

@@ -17,8 +17,9 @@ import bench
 n, e = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda:0")
 ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, 32, 64, 64, dev)
-tile = int(os.environ.get("RGCN_TILE", P.choose_tile(n, e, 32, 64, 64)))
-chunk = int(os.environ.get('RGCN_CHUNK', 64))
+_t, _c = P.choose_layout(n, e, 32, 64, 64)
+tile = int(os.environ.get("RGCN_TILE", _t))
+chunk = int(os.environ.get('RGCN_CHUNK', _c))
 plans = P.build_graph_plans(ei, et, n, 32, tile, chunk=chunk)
 print("tile", tile)
 fp = plans.fwd
