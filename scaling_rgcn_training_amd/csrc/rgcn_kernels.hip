@@ -43,6 +43,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #ifndef RGCN_PRIO
 #define RGCN_PRIO 3
 #endif
+// cache policy of the direct dW kernel's x-row gathers (aux bits of buffer_load): 0 default, 2 = nt (streamed once)
+#ifndef RGCN_DW_X_AUX
+#define RGCN_DW_X_AUX 0
+#endif
 // run-time ablations of the tile kernel (1 skip MFMA + accumulate, 2 skip DMA, 4 skip B loads): only in diagnostic
 // builds (-DRGCN_DEBUG_KNOBS, set through rgcn_debug_set_mode); the product library has no such switch
 #ifdef RGCN_DEBUG_KNOBS
@@ -1484,7 +1488,7 @@ __global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) 
         }
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
-            o.a4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)ih[s], rbx) + colb), 0, 0));
+            o.a4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)ih[s], rbx) + colb), 0, RGCN_DW_X_AUX));
             o.g4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(__umul24((unsigned)ig[s], rbg) + colb), 0, 0));
         }
     };

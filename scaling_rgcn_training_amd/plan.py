@@ -210,27 +210,47 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags)
 
 
+import os as _os
+_WALK_MODE = _os.environ.get("RGCN_WALK", "sorted")   # experiment knob (read once at import): sorted | rr | phase
 DW_WALKERS = 2048   # waves that walk rel_order side by side in the largest dW launch (512 workgroups x 4 waves)
 
 
-def interleave_walk(units: Tensor, unit_rel: Tensor, r1: int, walkers: int = DW_WALKERS) -> Tensor:
-    """Order of the weight-gradient walk.  ``units`` arrive sorted by (relation, tile).  A dW launch hands every wave
-    one CONTIGUOUS range of the walk (few relation changes = few accumulator flushes), so with the plain sorted
-    order the ~``walkers`` concurrent waves sit at ``walkers`` different tiles and every upstream-gradient row a slot
-    gathers comes from HBM: E * 4 * out bytes per launch although only N rows exist (55 GB instead of 29 GB at the
-    headline config, profiles/r01h_pmc_traffic.json).  Here the units of relation r (U_r of them, rank q by tile) are
-    dealt ROUND-ROBIN over J_r = round(U_r * walkers / n_units) pieces of consecutive positions -- piece q mod J_r,
-    place q div J_r -- so every piece sweeps the whole tile sequence and all pieces (of all relations) pass the same
-    tiles at the same time: a gradient row is fetched from HBM once and served to the other ~R' relations' waves from
-    L2 / the Infinity Cache.  Relations stay contiguous and ascending (what the slab reduction relies on); any order
-    inside a relation gives the same sums up to fp32 re-association.  Pure integer arithmetic, restated by the HIP
-    plan builder (csrc/rgcn_plan.hip)."""
+def interleave_walk(units: Tensor, unit_rel: Tensor, r1: int, walkers: int = DW_WALKERS, mode: Optional[str] = None) -> Tensor:
+    """Order of the weight-gradient walk.  ``units`` arrive sorted by (relation, tile); a dW launch hands every wave
+    one CONTIGUOUS range of the walk (few relation changes = few accumulator flushes).
+
+    ``sorted`` (the product default) keeps that order.  ``rr`` and ``phase`` are the two interleaves tried in round 2
+    to let L2 / the Infinity Cache serve the gathered upstream-gradient rows (E * 4 * out bytes per launch although
+    only N rows exist: 55 GB moved for a 29 GB job at the headline config): the units of relation r are dealt over the
+    ~``walkers`` concurrent waves so that all of them pass the same tiles at the same point of their walk (``rr``:
+    round-robin over J_r = round(U_r * walkers / n) pieces; ``phase``: exactly aligned with the waves' ranges).
+    Measured (tools/debug/dw_walk_experiment.py, 10M / 100M / 32, 64 -> 64): sorted 9.44 ms, rr 10.00, phase 9.51, and
+    the same with nt loads on the x rows (9.33 / 9.92 / 9.31) -- no gain: ~5.5 TB/s of gathers push 256 MiB through the
+    memory-side cache every ~46 us, i.e. a row survives about four walk steps of the 2,048 waves, while free-running
+    waves drift apart by far more than that.  Relations stay contiguous and ascending in every mode
+    (what the slab reduction relies on); any order inside a relation gives the same sums up to fp32 re-association."""
     n = int(units.shape[0])
     if n == 0:
         return units
     dev = units.device
+    mode = mode or _WALK_MODE
+    if mode == "sorted":
+        return units
     cnt = torch.bincount(unit_rel, minlength=r1)                       # U_r
     start = torch.cumsum(cnt, 0) - cnt                                  # A_r
+    if mode == "phase":
+        # walker w owns positions [w n / walkers, (w + 1) n / walkers): the PHASE of position p is how far into its
+        # walker's range it lies, frac(p * walkers / n) = ((p * walkers) mod n) / n.  Inside a relation the k-th
+        # position in (phase, p) order takes the relation's k-th unit in tile order, so every walker -- also one
+        # that straddles two relations -- passes tile fraction ~phase at the same point of its own walk.
+        p = torch.arange(n, device=dev)
+        phase = (p * walkers) % n
+        o1 = torch.sort(phase, stable=True)[1]
+        o2 = torch.sort(unit_rel[o1], stable=True)[1]
+        pos = o1[o2]                                                    # positions, relation-major, by (phase, p)
+        out = torch.empty_like(units)
+        out[pos] = units
+        return out
     pieces = torch.clamp((cnt * walkers + n // 2) // n, min=1)          # J_r
     q = torch.arange(n, device=dev) - start[unit_rel]
     jr, ur = pieces[unit_rel], cnt[unit_rel]
@@ -358,25 +378,35 @@ def balanced_ranges(counts_per_tile: Tensor, world: int, tile: int, n_nodes: int
 # ------------------------------------------------------------------------------------------
 # plan cache, keyed on the identity of the tensors the caller passes every forward
 # ------------------------------------------------------------------------------------------
-_CACHE: Dict[tuple, tuple] = {}
+_CACHE: Dict[tuple, tuple] = {}     # insertion-ordered: least recently used first
 _CACHE_MAX = 16
+_CACHE_MAX_BYTES = int(float(_os.environ.get("RGCN_PLAN_CACHE_GB", "48")) * (1 << 30))   # read once at import
+
+
+def _plans_nbytes(plans) -> int:
+    pieces = getattr(plans, "pieces", None) or [plans]
+    return sum(p.fwd.nbytes() + p.bwd.nbytes() for p in pieces)
 
 
 def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
                        tile: int, aggr: str, builder=None, extra_key=(), chunk: int = CHUNK) -> GraphPlans:
+    """LRU over (edge tensors' identity, layout): at most ``_CACHE_MAX`` entries and ``RGCN_PLAN_CACHE_GB`` (48) GiB of
+    plan arrays (4.3 GB per 100M edges), least recently used evicted first."""
     key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
            edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr) + tuple(extra_key)
-    hit = _CACHE.get(key)
+    hit = _CACHE.pop(key, None)
     if hit is not None:
+        _CACHE[key] = hit           # most recently used last
         return hit[0]
     if builder is None:
         plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk)
     else:
         plans = builder()
-    if len(_CACHE) >= _CACHE_MAX:
+    nbytes = _plans_nbytes(plans)
+    while _CACHE and (len(_CACHE) >= _CACHE_MAX or sum(v[3] for v in _CACHE.values()) + nbytes > _CACHE_MAX_BYTES):
         _CACHE.pop(next(iter(_CACHE)))
     # hold the key tensors so their storage (and data_ptr) cannot be recycled while cached
-    _CACHE[key] = (plans, edge_index, edge_type)
+    _CACHE[key] = (plans, edge_index, edge_type, nbytes)
     return plans
 
 

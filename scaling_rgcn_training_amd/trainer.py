@@ -105,10 +105,23 @@ class Trainer:
         if self.verbose:
             print("weight transfer done")
 
+    def _device_data(self, graph):
+        """``graph.training_data`` on the training device, moved ONCE per (graph, device): the layer's graph plans are
+        cached on the identity of the edge tensors, so a fresh copy per call (what ``Data.to`` returns) would rebuild
+        them for the final test evaluation and keep the old copies alive."""
+        cached = getattr(graph, "_device_data", None)
+        if cached is None or cached[0] != self.device or cached[1] is not graph.training_data:
+            cached = (self.device, graph.training_data, graph.training_data.to(self.device))
+            try:
+                graph._device_data = cached
+            except AttributeError:
+                pass
+        return cached[2]
+
     def train(self, model: nn.Module, graph, loss_f: Callable, activation: Callable,
               sum_graph: bool = True) -> Tuple[List[float], List[float], List[float], List[float]]:
         model = model.to(self.device)
-        training_data = graph.training_data.to(self.device)
+        training_data = self._device_data(graph)
         optimizer = torch.optim.Adam(model.parameters(), lr=self.lr, weight_decay=self.weight_d)
         accuracies, losses, f1_ws, f1_ms = [], [], [], []
         targets = training_data.y_train.to(torch.float32)
@@ -158,6 +171,6 @@ class Trainer:
         loss_f, activation = get_losst(configs["dataset"], sumModel=False)
         acc["accuracy"], loss["loss"], f1_w["f1 weighted"], f1_m["f1 macro"] = self.train(
             orgModel, org, loss_f, activation, sum_graph=False)
-        td = org.training_data.to(self.device)
+        td = self._device_data(org)
         test_acc, test_f1_w, test_f1_m = evaluate(orgModel, activation, td, td.x_test, td.y_test, report=self.verbose)
         return acc, loss, f1_w, f1_m, test_acc, test_f1_w, test_f1_m, orgModel

@@ -83,11 +83,58 @@ def test_full_size_sampled_rows_match_oracle(big):
     assert_close(xg.grad[rows].cpu().numpy(), refx, condx, "dX rows")
     big["out"], big["dx"] = out.detach(), xg.grad
     big["dw"], big["droot"], big["dbias"] = conv.weight.grad.clone(), conv.root.grad.clone(), conv.bias.grad.clone()
-    # d_bias is the column sum of dOut; d_root = X^T dOut (float64 on the device)
-    np.testing.assert_allclose(big["dbias"].cpu().numpy(), big["dg"].double().sum(0).cpu().numpy(), rtol=2e-4, atol=0.5)
-    droot_ref = (x.double().T @ big["dg"].double()).cpu().numpy()
-    np.testing.assert_allclose(big["droot"].cpu().numpy(), droot_ref, rtol=2e-4, atol=1.0)
-    assert torch.all(torch.isfinite(big["dw"]))
+    # ---- weight gradients at full size, against float64 on the device with plain torch ops (independent of the
+    # plan): d_bias = column sums of dOut, d_root = X^T dOut, d_weight[r] = H_r^T dOut for the first relation, the
+    # last one and a random one (~3.1M edges each).  Criterion: the a-priori bound of oracle/tolerance.py (flat 1e-5
+    # + 4 u cond) AND no worse than the STOCK fp32 path on the same sums -- rocBLAS / ATen fp32 evaluations of the
+    # same products stand in for the reference's CPU loop, which cannot run at this size.
+    from oracle.tolerance import SLACK_LOG
+    dg, ei, et = big["dg"], big["ei"], big["et"]
+    U = 2.0 ** -24
+
+    def check(name, got, ref64, cond64, stock32):
+        err = (got.double() - ref64).abs()
+        flat = 1e-5 + 1e-5 * ref64.abs()
+        assert torch.all(err <= flat + 4 * U * cond64), (name, float((err - flat - 4 * U * cond64).max()))
+        excess, stock_err = float((err - flat).max()), float((stock32.double() - ref64).abs().max())
+        assert excess <= 4 * stock_err, f"{name}: excess over flat 1e-5 {excess:.3e} > 4 x the stock fp32 path's error {stock_err:.3e}"
+        SLACK_LOG.append((f"full-size {name}", excess, stock_err))
+
+    check("d_bias", big["dbias"], dg.double().sum(0), dg.double().abs().sum(0), dg.sum(0))
+    check("d_root", big["droot"], x.double().T @ dg.double(), x.double().abs().T @ dg.double().abs(), x.T @ dg)
+    cnt = torch.bincount(ei[1] * R + et, minlength=N * R)
+    for r in (0, R - 1, 13):
+        idx = torch.nonzero(et == r).squeeze(1)
+        s, d = ei[0][idx], ei[1][idx]
+        we = 1.0 / cnt[d * R + r].double()
+        h64 = x[s].double() * we[:, None]
+        g64 = dg[d].double()
+        check(f"d_weight[{r}]", big["dw"][r], h64.T @ g64, h64.abs().T @ g64.abs(), (x[s] * we.float()[:, None]).T @ dg[d])
+        del h64, g64
+
+
+def test_full_size_weight_gradients_linear_in_dout(big):
+    """d_weight / d_root / d_bias are linear in dOut: grads(2 g) == 2 grads(g) bit for bit (scaling by two is exact in
+    binary floating point and every kernel sums in a fixed order), and grads(g1 + g2) == grads(g1) + grads(g2) up to
+    fp32 rounding of the sums."""
+    conv, x, ei, et = big["conv"], big["x"], big["ei"], big["et"]
+
+    def grads(g):
+        xg = x.detach().requires_grad_(False)
+        conv.zero_grad()
+        conv(xg, ei, et).backward(g)
+        return [conv.weight.grad.clone(), conv.root.grad.clone(), conv.bias.grad.clone()]
+
+    g1 = big["dg"]
+    g2 = torch.roll(g1, 7, 0)
+    a, b, two, both = grads(g1), grads(g2), grads(2.0 * g1), grads(g1 + g2)
+    for base, ref in zip(a, (big["dw"], big["droot"], big["dbias"])):
+        assert torch.equal(base, ref), "run-to-run determinism of the weight gradients"
+    for u, v in zip(two, a):
+        assert torch.equal(u, 2.0 * v)
+    for u, v, w in zip(both, a, b):
+        scale = float(torch.maximum(v.abs(), w.abs()).max())
+        assert float((u - (v + w)).abs().max()) <= 2e-5 * scale + 1e-3, float((u - (v + w)).abs().max())
 
 
 def test_full_size_linearity_and_determinism(big):

@@ -232,7 +232,10 @@ def test_dw_walk_interleave():
     rel = torch.repeat_interleave(torch.arange(r1), cnt)
     units = torch.arange(rel.numel())                  # unit id == rank in the (relation, tile) order
     walkers = 64
-    out = interleave_walk(units, rel, r1, walkers=walkers)
+    out = interleave_walk(units, rel, r1, walkers=walkers, mode="rr")
+    assert torch.equal(interleave_walk(units, rel, r1, walkers=walkers, mode="sorted"), units)
+    ph = interleave_walk(units, rel, r1, walkers=walkers, mode="phase")
+    assert sorted(ph.tolist()) == units.tolist() and torch.all(rel[ph][1:] >= rel[ph][:-1])
     assert sorted(out.tolist()) == units.tolist()
     assert torch.all(rel[out][1:] >= rel[out][:-1])
     n = int(rel.numel())
@@ -247,4 +250,4 @@ def test_dw_walk_interleave():
         want = [q for j in range(j_r) for q in range(j, u, j_r)]
         assert seg == want
     # few walkers or few units: identity
-    assert torch.equal(interleave_walk(units[:40], rel[:40], r1, walkers=2048), units[:40])
+    assert torch.equal(interleave_walk(units[:40], rel[:40], r1, walkers=2048, mode="rr"), units[:40])

@@ -1,0 +1,28 @@
+"""CPU twins of the model wrappers (TEST INFRASTRUCTURE): the same ``Emb_*_Layers`` module with its two
+``RGCNConv`` layers replaced by ``OracleConv`` -- the oracle's restatement of PyG's per-relation loop
+(oracle/rgcn_oracle.py, the ops the reference executes on CPU) under autograd -- and identical parameters."""
+import copy
+
+import torch
+from torch import nn
+
+from oracle import rgcn_oracle as O
+
+
+class OracleConv(nn.Module):
+    def __init__(self, conv):
+        super().__init__()
+        self.weight = nn.Parameter(conv.weight.detach().cpu().clone(), requires_grad=conv.weight.requires_grad)
+        self.root = nn.Parameter(conv.root.detach().cpu().clone(), requires_grad=conv.root.requires_grad)
+        self.bias = nn.Parameter(conv.bias.detach().cpu().clone(), requires_grad=conv.bias.requires_grad)
+
+    def forward(self, x, edge_index, edge_type):
+        return O.rgcn_conv_loop(x, edge_index, edge_type, self.weight, self.root, self.bias)
+
+
+def cpu_twin(model):
+    """deep copy on the CPU with oracle convolutions and the unfused tail (F.relu / activation as torch ops)"""
+    twin = copy.deepcopy(model).cpu()
+    twin.rgcn1, twin.rgcn2 = OracleConv(model.rgcn1), OracleConv(model.rgcn2)
+    twin.fuse_activations = False
+    return twin
