@@ -94,6 +94,55 @@ typedef struct rgcn_plan {
 int rgcn_abi_version(void);
 const char* rgcn_status_string(int status);
 
+/* ---- graph plan, built on the device ---------------------------------------------------------------------------
+ * The COO the reference's Graph.init_graph produces and hands to every forward call (graphs/graph.py:55-69):
+ * int64, unsorted, duplicate triples kept, forward / inverse edges interleaved.  edge_index[0] / [1] / edge_type
+ * are rows of a TRANSPOSED [E, 3] tensor there, hence the element strides.  PyG rebuilds per-relation masks and
+ * counts from it on every call; here it is laid out once. */
+typedef struct rgcn_graph {
+    const int64_t* src;  /* edge_index[0]: source j of edge j -> i */
+    const int64_t* dst;  /* edge_index[1]: target i */
+    const int64_t* type; /* edge_type, 0 .. num_relations - 1 */
+    int64_t src_stride, dst_stride, type_stride; /* in elements */
+    int64_t num_edges;
+    int32_t num_nodes;
+    int32_t num_relations;
+} rgcn_graph_t;
+
+/* What rgcn_plan_build_begin found: sizes of the arrays the caller allocates for rgcn_plan_build_finish. */
+typedef struct rgcn_plan_sizes {
+    int32_t n_tiles;  /* tile_ptr: n_tiles + 1 */
+    int32_t n_chunks; /* chunk_rel / chunk_cnt / chunk_tile / chunk_flags */
+    int32_t n_units;  /* rel_order */
+    int32_t reserved;
+    int64_t n_slots;  /* slot_src / slot_w / slot_row / slot_acc: n_chunks * chunk */
+    int64_t n_edges;  /* edges placed (scatter node inside the owned range), before duplicate triples are merged */
+    uint64_t opaque[16]; /* state handed from _begin to _finish */
+} rgcn_plan_sizes_t;
+
+/* Bytes of scratch for rgcn_edge_weights / rgcn_plan_build_* on a graph of num_edges edges whose plan owns n_owned
+ * output nodes (0 on bad arguments).  The same workspace serves all three; it is dead after _finish. */
+size_t rgcn_plan_workspace_bytes(int64_t num_edges, int32_t n_owned, int32_t num_relations, int32_t tile);
+
+/* w[e] = 1 / max(1, c[dst_e, type_e]) for aggr = mean (c counts duplicates: PyG's scatter-mean normaliser), 1 for
+ * aggr = sum (aggr_sum != 0); float32, in input edge order.  Shared by the forward and the transposed plan.
+ * SYNCHRONISES the stream (reads a data-dependent count back); RGCN_ERR_GRAPH on out-of-range ids. */
+int rgcn_edge_weights(const rgcn_graph_t* graph, int aggr_sum, float* w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Plan of the edges scattering into nodes [node_begin, node_end) (node_begin a multiple of tile).
+ * transposed = 0: forward plan (gather source rows, scatter into targets) for rgcn_fwd / rgcn_bwd_dw;
+ * transposed = 1: the plan rgcn_bwd_dx runs on (gather target rows, scatter into sources), same weights w.
+ * _begin sorts, merges duplicate triples and sizes the plan (SYNCHRONISES the stream: the sizes are data-dependent);
+ * the caller then allocates the ten device arrays of `plan` (sizes above; nothing in this library allocates) and
+ * _finish fills them and the scalar fields, asynchronously on `stream`.  tile: output nodes per tile (multiple of
+ * 16), chunk: 64 or 128.  Replaces scaling_rgcn_training_amd/plan.py (torch tensor ops), which stays as the test
+ * oracle: all arrays are bit-identical. */
+int rgcn_plan_build_begin(const rgcn_graph_t* graph, const float* w, int transposed, int32_t node_begin, int32_t node_end,
+                          int32_t tile, int32_t chunk, void* workspace, size_t workspace_bytes, rgcn_plan_sizes_t* sizes,
+                          void* stream);
+int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* workspace, size_t workspace_bytes, rgcn_plan_t* plan,
+                           void* stream);
+
 /* Widths are padded to 16/32/64/128 inside the kernels; returns that padded value (0 if unsupported). */
 int rgcn_padded_width(int width);
 

@@ -19,6 +19,7 @@ ABI_VERSION = 8
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
     "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_act_backward", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
+    "rgcn_plan_workspace_bytes", "rgcn_edge_weights", "rgcn_plan_build_begin", "rgcn_plan_build_finish",
 )
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
@@ -35,6 +36,19 @@ class RgcnPlanStruct(C.Structure):
         ("chunk_tile", C.c_void_p), ("chunk_flags", C.c_void_p), ("rel_order", C.c_void_p), ("slot_src", C.c_void_p),
         ("slot_w", C.c_void_p), ("slot_row", C.c_void_p), ("slot_acc", C.c_void_p),
     ]
+
+
+class RgcnGraphStruct(C.Structure):
+    """struct rgcn_graph: the int64 COO exactly as the caller holds it (strided views allowed)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("type", C.c_void_p),
+                ("src_stride", C.c_int64), ("dst_stride", C.c_int64), ("type_stride", C.c_int64),
+                ("num_edges", C.c_int64), ("num_nodes", C.c_int32), ("num_relations", C.c_int32)]
+
+
+class RgcnPlanSizes(C.Structure):
+    """struct rgcn_plan_sizes"""
+    _fields_ = [("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("n_units", C.c_int32), ("reserved", C.c_int32),
+                ("n_slots", C.c_int64), ("n_edges", C.c_int64), ("opaque", C.c_uint64 * 16)]
 
 
 class RgcnLibraryError(RuntimeError):
@@ -76,6 +90,16 @@ def load() -> C.CDLL:
     lib.rgcn_bwd_dw_workspace_bytes.argtypes = [C.POINTER(RgcnPlanStruct), i32, i32]
     lib.rgcn_bwd_dw.restype = i32
     lib.rgcn_bwd_dw.argtypes = [C.POINTER(RgcnPlanStruct), vp, i32, i32, vp, i32, i32, vp, sz, vp, vp, vp, u32, vp]
+    i64 = C.c_int64
+    lib.rgcn_plan_workspace_bytes.restype = sz
+    lib.rgcn_plan_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    lib.rgcn_edge_weights.restype = i32
+    lib.rgcn_edge_weights.argtypes = [C.POINTER(RgcnGraphStruct), i32, vp, vp, sz, vp]
+    lib.rgcn_plan_build_begin.restype = i32
+    lib.rgcn_plan_build_begin.argtypes = [C.POINTER(RgcnGraphStruct), vp, i32, i32, i32, i32, i32, vp, sz,
+                                          C.POINTER(RgcnPlanSizes), vp]
+    lib.rgcn_plan_build_finish.restype = i32
+    lib.rgcn_plan_build_finish.argtypes = [C.POINTER(RgcnPlanSizes), vp, sz, C.POINTER(RgcnPlanStruct), vp]
     if lib.rgcn_abi_version() != ABI_VERSION:
         raise RgcnLibraryError(f"ABI version mismatch: library {lib.rgcn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
@@ -165,3 +189,62 @@ def bwd_dw(ps: RgcnPlanStruct, x: torch.Tensor, din: int, g: torch.Tensor, dout:
         check(lib.rgcn_bwd_dw(C.byref(ps), x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0), dout,
                               ws.data_ptr(), nbytes, _ptr(d_weight), _ptr(d_root), _ptr(d_bias), int(flags), _stream(x)),
               "rgcn_bwd_dw")
+
+
+# ---- graph plan, built on the device (rgcn_plan.hip) --------------------------------------------------------------
+def graph_struct(edge_index: torch.Tensor, edge_type: torch.Tensor, n_nodes: int, num_relations: int):
+    """(struct rgcn_graph, tensors it points into).  int64 device tensors are passed as they are -- strided views such
+    as the rows of the reference's transposed [E, 3] edge tensor included; other integer dtypes are converted."""
+    src, dst = edge_index[0], edge_index[1]
+    if src.dtype != torch.int64:
+        src, dst = src.long(), dst.long()
+    typ = edge_type if edge_type.dtype == torch.int64 else edge_type.long()
+    if src.device.type != "cuda" or typ.device != src.device:
+        raise RgcnLibraryError("the graph must live on the GPU")
+    e = int(typ.shape[0])
+    g = RgcnGraphStruct(src.data_ptr() if e else None, dst.data_ptr() if e else None, typ.data_ptr() if e else None,
+                        src.stride(0) if e else 1, dst.stride(0) if e else 1, typ.stride(0) if e else 1,
+                        e, int(n_nodes), int(num_relations))
+    return g, (src, dst, typ)
+
+
+def plan_workspace(num_edges: int, n_owned: int, num_relations: int, tile: int, device) -> torch.Tensor:
+    n = load().rgcn_plan_workspace_bytes(int(num_edges), int(n_owned), int(num_relations), int(tile))
+    if n == 0:
+        raise RgcnLibraryError("rgcn_plan_workspace_bytes: bad arguments")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def edge_weights(graph: RgcnGraphStruct, aggr: str, ws: torch.Tensor) -> torch.Tensor:
+    if aggr not in ("mean", "sum", "add"):
+        raise ValueError(f"unsupported aggr {aggr!r}")
+    w = torch.empty(max(int(graph.num_edges), 1), dtype=torch.float32, device=ws.device)
+    with torch.cuda.device(ws.device):
+        check(load().rgcn_edge_weights(C.byref(graph), int(aggr != "mean"), w.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _stream(ws)), "rgcn_edge_weights")
+    return w[:int(graph.num_edges)]
+
+
+def plan_build(graph: RgcnGraphStruct, w: torch.Tensor, transposed: bool, node_begin: int, node_end: int, tile: int,
+               chunk: int, ws: torch.Tensor):
+    """-> (RgcnPlanStruct, dict of the ten device arrays, n_edges placed)"""
+    lib, dev = load(), ws.device
+    sizes = RgcnPlanSizes()
+    with torch.cuda.device(dev):
+        check(lib.rgcn_plan_build_begin(C.byref(graph), w.data_ptr() if graph.num_edges else None, int(transposed),
+                                        int(node_begin), int(node_end), int(tile), int(chunk), ws.data_ptr(), ws.numel(),
+                                        C.byref(sizes), _stream(ws)), "rgcn_plan_build_begin")
+        i32 = dict(dtype=torch.int32, device=dev)
+        arr = {
+            "tile_ptr": torch.empty(sizes.n_tiles + 1, **i32), "chunk_rel": torch.empty(sizes.n_chunks, **i32),
+            "chunk_cnt": torch.empty(sizes.n_chunks, **i32), "chunk_tile": torch.empty(sizes.n_chunks, **i32),
+            "chunk_flags": torch.empty(sizes.n_chunks, **i32), "rel_order": torch.empty(sizes.n_units, **i32),
+            "slot_src": torch.empty(sizes.n_slots, **i32), "slot_w": torch.empty(sizes.n_slots, dtype=torch.float32, device=dev),
+            "slot_row": torch.empty(sizes.n_slots, **i32), "slot_acc": torch.empty(sizes.n_slots, **i32),
+        }
+        ps = RgcnPlanStruct()
+        for k, t in arr.items():
+            setattr(ps, k, t.data_ptr())
+        check(lib.rgcn_plan_build_finish(C.byref(sizes), ws.data_ptr(), ws.numel(), C.byref(ps), _stream(ws)),
+              "rgcn_plan_build_finish")
+    return ps, arr, int(sizes.n_edges)

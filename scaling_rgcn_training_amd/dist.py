@@ -54,8 +54,14 @@ class RankPlans:
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
                aggr: str, dctx: DistContext, chunk: int = 64) -> RankPlans:
-    """Plans of this rank's blocks.  The mean normaliser (a sort of all E keys) is computed ONCE, the edge list is
-    cut down to this rank's share ONCE per direction, and every piece is laid out from that share."""
+    """Plans of this rank's blocks.  The mean normaliser (a sort of all E keys) is computed ONCE and every piece is
+    laid out from the same edge list: on the GPU by the library's plan builder with the piece's node range (it keeps
+    the edges that scatter into the range), on the CPU (tests) by the torch form from this rank's share."""
+    ranges = [dctx.node_range(s, n_nodes) for s in range(dctx.pieces)]
+    if edge_type.device.type == "cuda":
+        from .plan import build_graph_plans_device
+        return RankPlans(build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
+                                                  ranges=[(r, r) for r in ranges]))
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = edge_type.to(torch.int64)
     w = edge_weights(src, dst, rel, num_relations, aggr)
@@ -69,8 +75,7 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
     fg, fs, fr, fw, fpiece = share(dst, src)       # forward: edges INTO my blocks
     bg, bs, br, bw, bpiece = share(src, dst)       # transposed: edges OUT OF my blocks
     out = []
-    for s in range(dctx.pieces):
-        b, e = dctx.node_range(s, n_nodes)
+    for s, (b, e) in enumerate(ranges):
         fm, bm = fpiece == s, bpiece == s
         fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk)
         bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk)

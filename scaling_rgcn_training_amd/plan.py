@@ -62,7 +62,8 @@ class TilePlan:
                           #   arrays, chunk u // (chunk // 64)), relation-major then tile: the dW kernels' walk
     slot_src: Tensor      # int32 [n_chunks * chunk]
     slot_w: Tensor        # float32 [n_chunks * chunk]
-    slot_dstl: Tensor     # int32 [n_chunks * chunk]  row inside the tile (padding: tile)
+    slot_dstl: Optional[Tensor]   # int32 [n_chunks * chunk]  row inside the tile (padding: tile); host-side checks only:
+                          #   None for plans built on the device
     slot_row: Tensor      # int32 [n_chunks * chunk]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
     slot_acc: Tensor      # int32 [n_chunks * chunk]  run-end position << 24 | accumulator row
     _keep: tuple = field(default=(), repr=False)
@@ -345,10 +346,12 @@ class GraphPlans:
     num_edges: int
 
 
-def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
-                      tile: int, aggr: str = "mean",
-                      fwd_range: Optional[Tuple[int, int]] = None,
-                      bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK) -> GraphPlans:
+def build_graph_plans_torch(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
+                            tile: int, aggr: str = "mean",
+                            fwd_range: Optional[Tuple[int, int]] = None,
+                            bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK) -> GraphPlans:
+    """The plans as torch tensor ops (any device): the TEST ORACLE of the device-side builder and what the CPU-only
+    tests walk with tests/plan_emulator.py."""
     src, dst = edge_index[0], edge_index[1]
     w = edge_weights(src, dst, edge_type, num_relations, aggr)
     fb, fe = fwd_range if fwd_range is not None else (0, n_nodes)
@@ -356,6 +359,62 @@ def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_r
     fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe, chunk)
     bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be, chunk)
     return GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(edge_type.shape[0]))
+
+
+def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, tile: int, chunk: int,
+                 node_begin: int, node_end: int, ws) -> TilePlan:
+    from . import _lib
+    if node_end <= node_begin:           # a block wholly past the last node (dist.py): nothing to lay out
+        z = lambda dt=torch.int32: torch.zeros(0, dtype=dt, device=ws.device)
+        return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_begin, num_relations=num_relations, tile=tile,
+                        chunk=chunk, n_tiles=0, n_chunks=0, n_edges=0, tile_ptr=torch.zeros(1, dtype=torch.int32, device=ws.device),
+                        chunk_rel=z(), chunk_cnt=z(), chunk_tile=z(), chunk_flags=z(), rel_order=z(), slot_src=z(),
+                        slot_w=z(torch.float32), slot_dstl=None, slot_row=z(), slot_acc=z())
+    ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, tile, chunk, ws)
+    plan = TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, tile=tile,
+                    chunk=chunk, n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None, **a)
+    plan._cstruct = ps
+    return plan
+
+
+def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
+                             aggr: str = "mean", fwd_range: Optional[Tuple[int, int]] = None,
+                             bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
+                             ranges=None):
+    """The plans built by the HIP library itself (csrc/rgcn_plan.hip through rgcn_edge_weights / rgcn_plan_build_*):
+    what every GPU forward uses.  ``ranges``: a list of (begin, end) owned ranges -> a list of GraphPlans that share one
+    edge-weight pass and one workspace (dist.py: one pair of plans per owned block)."""
+    from . import _lib
+    if chunk not in CHUNKS:
+        raise ValueError(f"chunk must be one of {CHUNKS}")
+    graph, keep = _lib.graph_struct(edge_index, edge_type, n_nodes, num_relations)
+    e = int(edge_type.shape[0])
+    rs = ranges if ranges is not None else [(fwd_range or (0, n_nodes), bwd_range or (0, n_nodes))]
+    own_max = max([1] + [max(f[1] - f[0], b[1] - b[0]) for f, b in rs])
+    ws = _lib.plan_workspace(e, own_max, num_relations, tile, edge_type.device)
+    try:
+        w = _lib.edge_weights(graph, aggr, ws)
+    except _lib.RgcnLibraryError as err:
+        if "out of range" in str(err):
+            raise ValueError("edge_index / edge_type out of range [0, num_nodes) / [0, num_relations)") from err
+        raise
+    out = []
+    for (fb, fe), (bb, be) in rs:
+        fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws)
+        bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws)
+        out.append(GraphPlans(fwd=fwd, bwd=bwd, num_edges=fwd.n_edges if ranges is not None else e))
+    del keep
+    return out if ranges is not None else out[0]
+
+
+def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
+                      tile: int, aggr: str = "mean",
+                      fwd_range: Optional[Tuple[int, int]] = None,
+                      bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK) -> GraphPlans:
+    """Device tensors: the HIP plan builder behind the C ABI.  CPU tensors (tests without a GPU): the torch form."""
+    if edge_type.device.type == "cuda" and _WALK_MODE == "sorted":
+        return build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk)
+    return build_graph_plans_torch(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk)
 
 
 def balanced_ranges(counts_per_tile: Tensor, world: int, tile: int, n_nodes: int):

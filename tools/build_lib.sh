@@ -1,12 +1,14 @@
 #!/bin/bash
 # Build librgcn_mi355x.so for gfx950 in-tree (cross-compiles without a GPU).  Usage: tools/build_lib.sh [--temps DIR]
+#   --temps DIR : also keep the .s files and print the register / LDS use of every kernel (tools/kernel_resources.py)
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-SRC="$ROOT/scaling_rgcn_training_amd/csrc/rgcn_kernels.hip"
-OUT="$ROOT/scaling_rgcn_training_amd/librgcn_mi355x.so"
-EXTRA=()
 if [[ "${1:-}" == "--temps" ]]; then
-  mkdir -p "$2"; cd "$2"; EXTRA=(-save-temps -Rpass-analysis=kernel-resource-usage)
+  mkdir -p "$2"; cd "$2"
+  for f in rgcn_kernels rgcn_plan; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -save-temps -Rpass-analysis=kernel-resource-usage \
+        "$ROOT/scaling_rgcn_training_amd/csrc/$f.hip" -o "$f.o" 2> "$f.resources.txt"
+  done
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "${EXTRA[@]}" "$SRC" -o "$OUT"
-echo "built $OUT"
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); import __graft_entry__ as g; g.build(force=True)"
+echo "built $ROOT/scaling_rgcn_training_amd/librgcn_mi355x.so"
