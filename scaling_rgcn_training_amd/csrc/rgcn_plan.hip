@@ -303,6 +303,13 @@ __global__ void head_flags_kernel(const u64* __restrict__ keys, u32 n, int shift
     flag[i] = (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1u : 0u;
 }
 
+// ex = exclusive scan of the head flags: for the head of a run that is the run's index, for the other elements of the
+// run it is the index + 1 (their head is already counted).  id[i] = ex[i] + flag[i] - 1 is the run index of EVERY element.
+__global__ void run_ids_kernel(u32* __restrict__ ex, const u32* __restrict__ flag, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ex[i] = ex[i] + flag[i] - 1u;
+}
+
 // duplicate (gather, scatter, relation) triples share ONE slot whose weight is the float64 sum of theirs
 __global__ void merge_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, u32 n, const u32* __restrict__ uidx,
                              u64* __restrict__ ukeys, u32* __restrict__ uvals) {
@@ -616,6 +623,7 @@ extern "C" int rgcn_edge_weights(const rgcn_graph_t* g, int aggr_sum, float* w, 
     if ((st = read_u32(ws.sb.sums + scan_blocks((u32)E), &n_runs, s)) != 0) return st;
     if ((st = read_u32(&ws.ctr->error, &err, s)) != 0) return st;
     if (err) return RGCN_ERR_GRAPH;
+    hipLaunchKernelGGL(run_ids_kernel, dim3(grid_for(E)), dim3(256), 0, s, ws.scan_b, ws.scan_a, (u32)E);
     u32* rstart = (u32*)ws.sb.k[cur ^ 1];        // the sort's spare key buffer: E + 1 words fit into E 8-byte keys
     hipLaunchKernelGGL(run_start_kernel, dim3(grid_for(E)), dim3(256), 0, s, ws.sb.k[cur], (u32)E, ws.scan_b, rstart, n_runs);
     hipLaunchKernelGGL(weights_out_kernel, dim3(grid_for(E)), dim3(256), 0, s, ws.sb.v[cur], (u32)E, ws.scan_b, rstart, w);
@@ -671,7 +679,8 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
                        ws.sb.v[ub]);
     // ---- groups = runs of equal (tile, relation) ------------------------------------------------------------------
     hipLaunchKernelGGL(head_flags_kernel, dim3(grid_for(n_unique)), dim3(256), 0, s, ws.sb.k[ub], n_unique, kl.gshift(), ws.scan_a);
-    exclusive_scan(ws.scan_a, ws.scan_b, n_unique, ws.sb.sums, s);           // scan_b = group id of every element
+    exclusive_scan(ws.scan_a, ws.scan_b, n_unique, ws.sb.sums, s);
+    hipLaunchKernelGGL(run_ids_kernel, dim3(grid_for(n_unique)), dim3(256), 0, s, ws.scan_b, ws.scan_a, n_unique);   // scan_b = group id
     u32 n_groups = 0;
     if ((st = read_u32(ws.sb.sums + scan_blocks(n_unique), &n_groups, s)) != 0) return st;
     if ((u64)n_groups + 1 > gmax) return RGCN_ERR_PLAN;
