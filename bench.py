@@ -10,17 +10,26 @@ SURVEY.md 8d (uniform src/dst/type, x ~ N(0,1), dOut ~ N(0,1)), generated on the
 A "step" is ONE pass of the hot path over the whole graph: RGCNConv.forward (weight pack + tile
 kernel) and its autograd backward (W^T pack + dX tile kernel on the transposed plan + dW kernel +
 slab reduction), called through the drop-in nn.Module exactly as reference model/layers.py does.
-The graph plan (sort / chunk layout) is built once before the timed region and reported separately
-(plan_build_s), as SURVEY.md 8d prescribes.  Inputs are resident in HBM when the clock starts.
+The graph plan (device-side sort / chunk layout, rgcn_plan_build_*) is built once before the timed region and
+reported separately (plan_build_s), as SURVEY.md 8d prescribes.  Inputs are resident in HBM when the clock starts.
+
+Timing: W untimed warm-up steps, then exactly K steps between barrier + synchronize pairs (value = E * K / that
+time, max over ranks); every timed step is also bracketed by HIP events on the launch stream, whose MEDIAN is
+reported beside it (20 warm-up + 50 timed iterations, median -- the defaults).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the SAME graph is
 edge-partitioned by destination range (strong scaling); every step includes the per-layer
-all-gathers and the weight-gradient all-reduce.  value = E * K / max-over-ranks time.
+all-gathers and the weight-gradient all-reduce; `comm` reports what they moved and how long the step waited on them.
 
-The JSON line also carries `roofline` for the dominant kernel (HIP-event timed per launch; algorithmic
-bytes and flops of SURVEY.md 8d / DESIGN.md; the binding roof is the one that needs more time at its peak -- at
-64 -> 64 in exact fp32 that is the fp32 MFMA peak, with the HBM figures beside it) and `cpu_baseline`: the oracle's PyG-loop restatement timed on this
-host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+The JSON line also carries
+  roofline       the dominant kernel (HIP-event timed per launch; algorithmic bytes and flops of SURVEY.md 8d /
+                 DESIGN.md; the binding roof is the one that needs more time at its peak -- at 64 -> 64 in exact
+                 fp32 that is the fp32 MFMA peak, with the HBM figures beside it)
+  roofline_step  the whole step against HBM: algorithmic bytes of fwd + bwd (92.1 GB at the headline config) / ms_per_step
+                 -- the number north_star's ">= 40 % of HBM roofline" refers to
+  ladder         GPU edges/s on the smaller rungs of SURVEY.md 8d ((100k, 1M), (1M, 10M), AIFB shape)
+  cpu_baseline   the oracle's PyG-loop restatement timed on this host's cores on the (1M, 10M) rung, beside the GPU
+                 figure of the SAME rung (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -28,6 +37,7 @@ import argparse
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
@@ -37,8 +47,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PMC_TRAFFIC_FILE = "r01h_pmc_traffic.json"   # newest committed PMC pass
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), 155 measured
+# HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE, then WRITE_SIZE; gfx950 correction): counters
+# cannot be read inside this process, so `roofline.traffic` quotes the newest committed pass and names it
+PMC_TRAFFIC_FILE = os.environ.get("RGCN_PMC_TRAFFIC_FILE", "r02_pmc_traffic.json")
+HEADLINE = (10_000_000, 100_000_000, 32, 64)
+LADDER = (("100k/1M", 100_000, 1_000_000, 32, 64, 64), ("1M/10M", 1_000_000, 10_000_000, 32, 64, 64),
+          ("AIFB shape 63->16", 8_243, 49_838, 89, 63, 16))
+CPU_RUNG = ("1M/10M", 1_000_000, 10_000_000)
 
 
 def algorithmic_bytes(e, n, r, din, dout):
@@ -72,16 +88,21 @@ def synthetic_on_device(n, e, r, din, dout, dev, seed=0):
     return torch.stack([src, dst]), typ, x, dout_grad, weight, root
 
 
-def cpu_baseline(r, din, dout, n=200_000, e=2_000_000, reps=2):
-    """The oracle's restatement of the PyG loop (the ops the reference executes on CPU), fwd + bwd."""
-    from oracle import rgcn_oracle as O
+def host_threads():
     # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole host and
     # oversubscribing ATen's OpenMP pool makes the loop crawl)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))
+    return max(1, min(avail, 16))
+
+
+def cpu_baseline(n, e, r, din, dout):
+    """The oracle's restatement of the PyG loop (the ops the reference executes on CPU), fwd + bwd, ONE pass
+    (about 10-30 s of CPU work at (1M, 10M): R' live [N, in] temporaries under autograd)."""
+    from oracle import rgcn_oracle as O
+    threads = host_threads()
     torch.set_num_threads(threads)
     ei, et = O.synthetic_graph(n, e, r, seed=0)
     w, root, bias = O.synthetic_params(r, din, dout, seed=0)
@@ -90,18 +111,12 @@ def cpu_baseline(r, din, dout, n=200_000, e=2_000_000, reps=2):
     dg = torch.randn(n, dout, generator=g)
     for t in (w, root, bias):
         t.requires_grad_(True)
-    best = float("inf")
-    for i in range(reps + 1):
-        for t in (x, w, root, bias):
-            t.grad = None
-        t0 = time.perf_counter()
-        out = O.rgcn_conv_loop(x, ei, et, w, root, bias)
-        out.backward(dg)
-        dt = time.perf_counter() - t0
-        if i > 0:
-            best = min(best, dt)
-    return {"value": e / best, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"synthetic {n} nodes / {e} edges / {r} relations, {din}->{dout}, fwd+bwd, best of {reps} "
+    t0 = time.perf_counter()
+    out = O.rgcn_conv_loop(x, ei, et, w, root, bias)
+    out.backward(dg)
+    dt = time.perf_counter() - t0
+    return {"value": e / dt, "unit": "edges/s", "cores": threads, "kind": "port", "seconds": dt,
+            "sample": f"synthetic {n} nodes / {e} edges / {r} relations, {din}->{dout}, fwd+bwd, one pass "
                       f"(PyG-loop restatement oracle/rgcn_oracle.py under autograd, torch {torch.__version__} CPU)"}
 
 
@@ -109,16 +124,48 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5):
+    """fwd + bwd of one layer through the drop-in module on a fresh synthetic graph: (median ms per step, plan s)"""
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    from scaling_rgcn_training_amd.plan import clear_plan_cache
+    ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, din, dout, dev, seed=1)
+    conv = RGCNConv(din, dout, r).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(weight)
+        conv.root.copy_(root)
+    x.requires_grad_(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    conv._plans(x, ei, et)
+    torch.cuda.synchronize()
+    plan_s = time.perf_counter() - t0
+    evs = []
+    for i in range(warmup + steps):
+        x.grad = None
+        conv.zero_grad(set_to_none=True)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        conv(x, ei, et).backward(dg)
+        b.record()
+        if i >= warmup:
+            evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = statistics.median(a.elapsed_time(b) for a, b in evs)
+    clear_plan_cache()
+    return ms, plan_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nodes", type=int, default=10_000_000)
-    ap.add_argument("--edges", type=int, default=100_000_000)
-    ap.add_argument("--relations", type=int, default=32)
-    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nodes", type=int, default=HEADLINE[0])
+    ap.add_argument("--edges", type=int, default=HEADLINE[1])
+    ap.add_argument("--relations", type=int, default=HEADLINE[2])
+    ap.add_argument("--width", type=int, default=HEADLINE[3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ladder", action="store_true")
     args = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -161,7 +208,7 @@ def main():
     torch.cuda.synchronize()
     plan_s = time.perf_counter() - t0
     _pl = [plans] if world == 1 else plans.pieces
-    log(f"plan built in {plan_s:.2f}s: fwd {sum(p.fwd.n_chunks for p in _pl)} chunks / "
+    log(f"plan built in {plan_s:.3f}s (device-side builder): fwd {sum(p.fwd.n_chunks for p in _pl)} chunks / "
         f"{sum(p.fwd.n_tiles for p in _pl)} tiles, bwd {sum(p.bwd.n_chunks for p in _pl)} chunks, "
         f"{sum(p.fwd.nbytes() + p.bwd.nbytes() for p in _pl) / 1e9:.2f} GB, tile {_pl[0].fwd.tile}")
 
@@ -178,19 +225,46 @@ def main():
 
     for i in range(args.warmup):
         step()
-        torch.cuda.synchronize()
-        log(f"warmup step {i} done")
+        if i < 3 or i == args.warmup - 1:
+            torch.cuda.synchronize()
+            log(f"warmup step {i} done")
+    dctx = conv.dist
+    if dctx is not None:
+        for k in ("all_gather", "all_gather_bytes", "all_reduce", "all_reduce_bytes"):
+            dctx.stats[k] = 0
+        dctx.stats["wait_events"] = []
+        dctx.time_waits = True
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for a, b in evs:
+        a.record()
         step()
+        b.record()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    log(f"{args.steps} timed steps: {dt / args.steps * 1e3:.2f} ms/step")
+    step_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    log(f"{args.steps} timed steps: {dt / args.steps * 1e3:.2f} ms/step (per-step HIP events: median "
+        f"{statistics.median(step_ms):.2f}, min {step_ms[0]:.2f}, max {step_ms[-1]:.2f})")
+    comm = None
+    if dctx is not None:
+        dctx.time_waits = False
+        st = dctx.stats
+        wait_ms = sum(a.elapsed_time(b) for a, b in st["wait_events"]) / args.steps
+        comm = {"backend": backend, "pieces": dctx.pieces,
+                "all_gather_per_step": st["all_gather"] / args.steps,
+                "all_gather_recv_bytes_per_step_per_rank": st["all_gather_bytes"] / args.steps,
+                "all_reduce_per_step": st["all_reduce"] / args.steps,
+                "all_reduce_bytes_per_step": st["all_reduce_bytes"] / args.steps,
+                "comm_bytes_per_step_per_rank": (st["all_gather_bytes"] + 2 * st["all_reduce_bytes"]) / args.steps,
+                "wait_ms_per_step": wait_ms,
+                "compute_ms_per_step": statistics.median(step_ms) - wait_ms,
+                "note": "wait_ms = HIP-event time the launch stream spent blocked on the collectives after the last "
+                        "piece's kernels were enqueued (rank 0); the collectives of earlier pieces overlap the kernels"}
 
     # ---- per-launch timing of the three hot kernels (HIP events on the launch stream) --------------
     fps = [plans.fwd] if world == 1 else [p.fwd for p in plans.pieces]
@@ -221,42 +295,42 @@ def main():
 
     launches = {"fwd": run_fwd, "dx": run_dx, "dw": run_dw}
     kernel_ms = {}
-    reps = max(3, min(args.steps, 10))
+    reps = max(5, min(args.steps, 20))
     for name, fn in launches.items():
         fn()
         torch.cuda.synchronize()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in evs:
+        kevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in kevs:
             a.record()
             fn()
             b.record()
         torch.cuda.synchronize()
-        kernel_ms[name] = sum(a.elapsed_time(b) for a, b in evs) / reps
-        log(f"launch {name}: {kernel_ms[name]:.3f} ms")
-    # the forward and dX launches run the same kernel (rgcn_tile_kernel); dw adds a memset + reduce
+        kernel_ms[name] = statistics.median(a.elapsed_time(b) for a, b in kevs)
+        log(f"launch {name}: {kernel_ms[name]:.3f} ms (median of {reps})")
+    # the forward and dX launches run the same kernel (rgcn_tile_kernel); dw = memsets + rgcn_dw_direct_kernel + reduce
     alg = algorithmic_bytes(e / world, n / world, r, d, d)
+    flops = algorithmic_flops(e / world, n / world, r, d, d)
     tile_ms = kernel_ms["fwd"] + kernel_ms["dx"]
     if tile_ms >= kernel_ms["dw"]:
-        kname, kbytes, kms = "rgcn_tile_kernel (fwd + dX launches)", (alg["fwd"] + alg["dx"]) / 2, tile_ms / 2
+        kname, prof_name = "rgcn_tile_kernel (fwd + dX launches)", "rgcn::rgcn_tile_kernel<64, 64"
+        kbytes, kflops, kms = (alg["fwd"] + alg["dx"]) / 2, (flops["fwd"] + flops["dx"]) / 2, tile_ms / 2
     else:
-        kname, kbytes, kms = "rgcn_dw_wide_kernel", alg["dw"], kernel_ms["dw"]
+        kname, prof_name = "rgcn_dw_direct_kernel (dW launch)", "rgcn::rgcn_dw_direct_kernel"
+        kbytes, kflops, kms = alg["dw"], flops["dw"], kernel_ms["dw"]
     hbm_achieved = kbytes / (kms * 1e-3) / 1e9
-    flops = algorithmic_flops(e / world, n / world, r, d, d)
-    kflops = (flops["fwd"] + flops["dx"]) / 2 if "tile" in kname else flops["dw"]
     mfma_achieved = kflops / (kms * 1e-3) / 1e12
     # Which roof binds: the kernels contract in exact fp32 on the matrix cores (tolerance 1e-5 rules out bf16), whose
     # dense peak is 1/16 of bf16's -- at 64 -> 64 the contraction needs more time at its peak than the gather at HBM's
     t_hbm, t_mfma = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_F32_PEAK_TFLOPS * 1e12)
-    # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs,
-    # gfx950 correction applied) committed under profiles/ -- only quoted for the workload they were taken on
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
-        if world == 1 and (n, e, r, d) == (10_000_000, 100_000_000, 32, 64):
-            want = "rgcn::rgcn_tile_kernel<64, 64" if "tile" in kname else "rgcn::rgcn_dw_wide_kernel<64, 64"
-            traffic = next(v["hbm_bytes_per_launch"] for k, v in pm["kernels"].items() if k.startswith(want))
+        if world == 1 and (n, e, r, d) == HEADLINE:
+            traffic = next(v["hbm_bytes_per_launch"] for k, v in pm["kernels"].items() if k.startswith(prof_name))
+            traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                              f"gfx950 FETCH_SIZE correction) of this command on an earlier run; not measured in this process")
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
     if t_mfma >= t_hbm:
         roofline = {"bound": "mfma", "kernel": kname, "achieved": mfma_achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
@@ -264,10 +338,17 @@ def main():
     else:
         roofline = {"bound": "hbm", "kernel": kname, "achieved": hbm_achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic}
-    roofline.update({"algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
+    roofline.update({"traffic_source": traffic_source, "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
                      "hbm_achieved_GBs": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
                      "t_at_peak_ms": {"hbm": t_hbm * 1e3, "mfma_f32": t_mfma * 1e3}})
+    ms_per_step = dt / args.steps * 1e3
+    step_bytes = sum(algorithmic_bytes(e, n, r, d, d).values())
+    roofline_step = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
+                     "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                     "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
+                     "target_frac": 0.40, "ms_per_step_at_target": step_bytes / (0.40 * HBM_PEAK_GBS * 1e9) * 1e3 / world}
 
+    rec = None
     if rank == 0:
         rec = {
             "metric": "edges/s per RGCN layer (fwd+bwd)",
@@ -276,7 +357,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
+            "ms_per_step_median": statistics.median(step_ms),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -287,13 +369,37 @@ def main():
                        "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
                        "partition": f"dst-range x{world}" if world > 1 else "none"},
             "roofline": roofline,
+            "roofline_step": roofline_step,
             "kernel_ms": kernel_ms,
             "plan_build_s": plan_s,
             "plan_bytes": sum(p.nbytes() for p in fps + bps),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            log("timing the CPU baseline sample")
-            rec["cpu_baseline"] = cpu_baseline(r, d, d)
+        if comm is not None:
+            rec["comm"] = comm
+    # ---- the smaller rungs and the CPU baseline beside its rung (N = 1 only) ----------------------------------------
+    if world == 1 and rank == 0:
+        from scaling_rgcn_training_amd.plan import clear_plan_cache
+        del plans, psf, psb, fps, bps, out, dxb, x, xd, dg, ei, et, conv, _pl
+        clear_plan_cache()
+        torch.cuda.empty_cache()
+        if not args.no_ladder:
+            ladder = [{"rung": "10M/100M", "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
+                       "gpu_ms_per_step": rec["ms_per_step_median"], "gpu_edges_per_s": e / (rec["ms_per_step_median"] * 1e-3)}]
+            for name, ln, le, lr, lin, lout in LADDER:
+                ms, ps_ = gpu_rung(ln, le, lr, lin, lout, dev)
+                ladder.append({"rung": name, "nodes": ln, "edges": le, "relations": lr, "in": lin, "out": lout,
+                               "gpu_ms_per_step": ms, "gpu_edges_per_s": le / (ms * 1e-3), "plan_build_s": ps_})
+                log(f"ladder {name}: {ms:.3f} ms/step = {le / (ms * 1e-3):.3e} edges/s")
+            rec["ladder"] = ladder
+        if not args.no_cpu_baseline:
+            log(f"timing the CPU baseline on the {CPU_RUNG[0]} rung (one pass, {host_threads()} threads)")
+            cb = cpu_baseline(CPU_RUNG[1], CPU_RUNG[2], r, d, d)
+            if not args.no_ladder:
+                same = next(l for l in rec["ladder"] if l["rung"] == CPU_RUNG[0])
+                cb["gpu_same_rung_edges_per_s"] = same["gpu_edges_per_s"]
+                cb["gpu_over_cpu_same_rung"] = same["gpu_edges_per_s"] / cb["value"]
+            rec["cpu_baseline"] = cb
+    if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

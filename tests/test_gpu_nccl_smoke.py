@@ -1,0 +1,86 @@
+"""RCCL on the one GPU of the test box (torch.distributed backend 'nccl', world_size 1): the process group comes up,
+the IN-PLACE all_gather_into_tensor the layer relies on (sendbuf == recvbuf + rank * count) runs on RCCL's stream, and
+the edge-partitioned layer -- its pieces, asynchronous collectives and fused gradient all-reduce -- gives the
+single-process result bit for bit.  (Two ranks cannot share one device under RCCL; the 2-rank rehearsal of the same
+code is tests/test_gpu_dist.py over gloo, the N-GPU run is the driver's.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from oracle import rgcn_oracle as O
+    from scaling_rgcn_training_amd import dist as rdist
+    from scaling_rgcn_training_amd.conv import DistContext, RGCNConv, tile_for
+    # (1) the aliasing of the layer's all-gather, on RCCL
+    full = torch.arange(4 * 6, dtype=torch.float32, device=dev).view(4, 6)
+    want = full.clone()
+    h = dist.all_gather_into_tensor(full, full[0:4], async_op=True)
+    h.wait()
+    flat = torch.ones(1000, device=dev)
+    dist.all_reduce(flat)
+    torch.cuda.synchronize()
+    assert torch.equal(full, want) and float(flat.sum()) == 1000.0
+    # (2) the partitioned layer over the nccl group (4 pieces, world 1) == the plain layer
+    n, e, r, din, dout = 3000, 40000, 6, 64, 64
+    ei, et = O.synthetic_graph(n, e, r, seed=2)
+    w, root, bias = O.synthetic_params(r, din, dout, seed=2)
+    g = torch.Generator().manual_seed(5)
+    x, dg = torch.randn(n, din, generator=g), torch.randn(n, dout, generator=g)
+
+    def run(partitioned):
+        conv = RGCNConv(din, dout, r).to(dev)
+        with torch.no_grad():
+            conv.weight.copy_(w); conv.root.copy_(root); conv.bias.copy_(bias + 0.25)
+        if partitioned:
+            assert rdist.make_context(n, 64) is None          # a 1-rank group needs no partition ...
+            tile = tile_for(din, dout, n, e, r)
+            conv.dist = DistContext(None, 0, 1, rdist.piece_rows(n, tile, 1, 4), 4)   # ... so force one: 4 pieces
+        xd = x.to(dev).requires_grad_(True)
+        out = conv(xd, ei.to(dev), et.to(dev))
+        out.backward(dg.to(dev))
+        torch.cuda.synchronize()
+        if partitioned:
+            assert conv.dist.stats["all_gather"] == 8 and conv.dist.stats["all_reduce"] == 1
+        return [t.cpu().numpy() for t in (out.detach(), xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad)]
+
+    single, part = run(False), run(True)
+    assert np.array_equal(single[0], part[0]) and np.array_equal(single[1], part[1])
+    for a, b in zip(single[2:], part[2:]):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-3)      # four partial sums instead of one
+    dist.destroy_process_group()
+    ret.put("ok")
+
+
+def test_rccl_world1_in_place_all_gather_and_partitioned_layer():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, p.exitcode
+    assert ret.get(timeout=5) == "ok"
