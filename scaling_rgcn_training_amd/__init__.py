@@ -11,6 +11,7 @@ Sub-modules:
 * ``trainer`` -- full-batch loop of reference model/modelTrainer.py (+ device-correct evaluation)
 * ``graphs``  -- N-Triples ingest, dataset assembly, summary -> original embedding transfer (graphs/*.py, embeddingTricks.py)
 * ``dist``    -- one-process-per-GPU edge partition + per-layer collective over RCCL
+* ``summaries`` -- attribute-summary generation (murmur3 x64-128 of predicate sets; graphs/createAttributeSum.py)
 
 There is no CPU compute path: the layer raises if the HIP library or a GPU is missing.
 """
@@ -33,4 +34,7 @@ def __getattr__(name):
     if name == "Trainer":
         from .trainer import Trainer
         return Trainer
+    if name in ("create_sum_map", "hash128"):
+        from . import summaries
+        return getattr(summaries, name)
     raise AttributeError(name)
