@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 8
+#define RGCN_ABI_VERSION 9
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -47,6 +47,8 @@ enum rgcn_act { RGCN_ACT_NONE = 0, RGCN_ACT_RELU = 1, RGCN_ACT_SIGMOID = 2 };
 #define RGCN_FLAG_POINTER_GATHER 1u /* address gathered rows with 64-bit pointers even where a buffer descriptor fits */
 #define RGCN_FLAG_DW_RING 2u        /* rgcn_bwd_dw: LDS-ring kernels whatever the size */
 #define RGCN_FLAG_DW_DIRECT 4u      /* rgcn_bwd_dw: direct-gather kernel whenever the widths allow (64 x 64) */
+#define RGCN_FLAG_EXACT_FP32 8u     /* rgcn_fwd / rgcn_bwd_dx: the exact-fp32 MFMA kernel also where the split-precision
+                                     * (bf16 x 3, six products: fp32-equivalent) kernel applies: 64 x 64 on layout-1 plans */
 
 enum rgcn_status {
     RGCN_OK = 0,
@@ -73,6 +75,11 @@ typedef struct rgcn_plan {
     int32_t n_chunks;
     int32_t chunk;         /* edge slots per chunk: 64 or 128 (rows of one LDS ring slot of the forward / dX kernel) */
     int32_t n_units;       /* entries of rel_order */
+    int32_t layout;        /* 0: the rows of a (tile, relation) group are dealt over all its row tiles; 1 (chunk = 128): SPLIT
+                            * placement -- a chunk's rows are cut at a change of destination into slots [0, 64) and [64, 128),
+                            * so its two halves scatter into disjoint rows (chunk_flags bit 8: they do not) and the
+                            * split-precision forward / dX kernel gives each half to its own pair of waves */
+    int32_t reserved;
     const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
     const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */
     const int32_t* chunk_cnt;  /* [n_chunks] slots of the chunk's used 16-slot MFMA row tiles (16, 32, ... chunk);
@@ -135,18 +142,19 @@ int rgcn_edge_weights(const rgcn_graph_t* graph, int aggr_sum, float* w, void* w
  * _begin sorts, merges duplicate triples and sizes the plan (SYNCHRONISES the stream: the sizes are data-dependent);
  * the caller then allocates the ten device arrays of `plan` (sizes above; nothing in this library allocates) and
  * _finish fills them and the scalar fields, asynchronously on `stream`.  tile: output nodes per tile (multiple of
- * 16), chunk: 64 or 128.  Replaces scaling_rgcn_training_amd/plan.py (torch tensor ops), which stays as the test
+ * 16), chunk: 64 or 128, layout: 0 or (chunk = 128) 1, see struct rgcn_plan.  Replaces scaling_rgcn_training_amd/plan.py (torch tensor ops), which stays as the test
  * oracle: all arrays are bit-identical. */
 int rgcn_plan_build_begin(const rgcn_graph_t* graph, const float* w, int transposed, int32_t node_begin, int32_t node_end,
-                          int32_t tile, int32_t chunk, void* workspace, size_t workspace_bytes, rgcn_plan_sizes_t* sizes,
-                          void* stream);
+                          int32_t tile, int32_t chunk, int32_t layout, void* workspace, size_t workspace_bytes,
+                          rgcn_plan_sizes_t* sizes, void* stream);
 int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* workspace, size_t workspace_bytes, rgcn_plan_t* plan,
                            void* stream);
 
 /* Widths are padded to 16/32/64/128 inside the kernels; returns that padded value (0 if unsupported). */
 int rgcn_padded_width(int width);
 
-/* Floats of the MFMA-fragment-ordered weight pack: (R' + 1) * pad(K) * pad(N). */
+/* Floats of the MFMA-fragment-ordered weight pack: (R' + 1) * pad(K) * pad(N), plus for 64 x 64 layers the bf16 x 3 split
+ * of the same weights ((R' + 1) * 6144 floats) that the split-precision kernel reads. */
 size_t rgcn_packed_weight_floats(int num_relations, int din, int dout);
 
 /* Pack weight[R', din, dout] (+ root[din, dout], may be NULL = zeros) into B-fragment order.

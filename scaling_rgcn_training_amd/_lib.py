@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
@@ -24,7 +24,7 @@ EXPORTS = (
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT = 1, 2, 4
+FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT, FLAG_EXACT_FP32 = 1, 2, 4, 8
 
 
 class RgcnPlanStruct(C.Structure):
@@ -32,6 +32,7 @@ class RgcnPlanStruct(C.Structure):
     _fields_ = [
         ("n_nodes", C.c_int32), ("n_owned", C.c_int32), ("num_relations", C.c_int32),
         ("tile", C.c_int32), ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("chunk", C.c_int32), ("n_units", C.c_int32),
+        ("layout", C.c_int32), ("reserved", C.c_int32),
         ("tile_ptr", C.c_void_p), ("chunk_rel", C.c_void_p), ("chunk_cnt", C.c_void_p),
         ("chunk_tile", C.c_void_p), ("chunk_flags", C.c_void_p), ("rel_order", C.c_void_p), ("slot_src", C.c_void_p),
         ("slot_w", C.c_void_p), ("slot_row", C.c_void_p), ("slot_acc", C.c_void_p),
@@ -96,7 +97,7 @@ def load() -> C.CDLL:
     lib.rgcn_edge_weights.restype = i32
     lib.rgcn_edge_weights.argtypes = [C.POINTER(RgcnGraphStruct), i32, vp, vp, sz, vp]
     lib.rgcn_plan_build_begin.restype = i32
-    lib.rgcn_plan_build_begin.argtypes = [C.POINTER(RgcnGraphStruct), vp, i32, i32, i32, i32, i32, vp, sz,
+    lib.rgcn_plan_build_begin.argtypes = [C.POINTER(RgcnGraphStruct), vp, i32, i32, i32, i32, i32, i32, vp, sz,
                                           C.POINTER(RgcnPlanSizes), vp]
     lib.rgcn_plan_build_finish.restype = i32
     lib.rgcn_plan_build_finish.argtypes = [C.POINTER(RgcnPlanSizes), vp, sz, C.POINTER(RgcnPlanStruct), vp]
@@ -121,6 +122,7 @@ def plan_struct(plan) -> RgcnPlanStruct:
         raise RgcnLibraryError("the graph plan must live on the GPU (plan tensors are on %s)" % plan.slot_src.device)
     plan._cstruct = RgcnPlanStruct(
         plan.n_nodes, plan.n_owned, plan.num_relations, plan.tile, plan.n_tiles, plan.n_chunks, plan.chunk, plan.n_units,
+        int(getattr(plan, "layout", 0)), 0,
         plan.tile_ptr.data_ptr(), plan.chunk_rel.data_ptr(), plan.chunk_cnt.data_ptr(),
         plan.chunk_tile.data_ptr(), plan.chunk_flags.data_ptr(), plan.rel_order.data_ptr(), plan.slot_src.data_ptr(),
         plan.slot_w.data_ptr(), plan.slot_row.data_ptr(), plan.slot_acc.data_ptr())
@@ -226,14 +228,14 @@ def edge_weights(graph: RgcnGraphStruct, aggr: str, ws: torch.Tensor) -> torch.T
 
 
 def plan_build(graph: RgcnGraphStruct, w: torch.Tensor, transposed: bool, node_begin: int, node_end: int, tile: int,
-               chunk: int, ws: torch.Tensor):
+               chunk: int, ws: torch.Tensor, split: bool = False):
     """-> (RgcnPlanStruct, dict of the ten device arrays, n_edges placed)"""
     lib, dev = load(), ws.device
     sizes = RgcnPlanSizes()
     with torch.cuda.device(dev):
         check(lib.rgcn_plan_build_begin(C.byref(graph), w.data_ptr() if graph.num_edges else None, int(transposed),
-                                        int(node_begin), int(node_end), int(tile), int(chunk), ws.data_ptr(), ws.numel(),
-                                        C.byref(sizes), _stream(ws)), "rgcn_plan_build_begin")
+                                        int(node_begin), int(node_end), int(tile), int(chunk), int(bool(split)), ws.data_ptr(),
+                                        ws.numel(), C.byref(sizes), _stream(ws)), "rgcn_plan_build_begin")
         i32 = dict(dtype=torch.int32, device=dev)
         arr = {
             "tile_ptr": torch.empty(sizes.n_tiles + 1, **i32), "chunk_rel": torch.empty(sizes.n_chunks, **i32),

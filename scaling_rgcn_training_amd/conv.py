@@ -55,6 +55,16 @@ def layout_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: i
     return (_ENV_TILE or tile), (_ENV_CHUNK or chunk)
 
 
+def split_for(in_channels: int, out_channels: int, n_nodes: int, n_edges: int, num_relations: int, tile: int, chunk: int) -> bool:
+    """Lay the plan out for the split-precision forward / dX kernel (plan layout 1)?  That kernel exists for layers padded
+    to 64 x 64 on 128-slot chunks and pays where a (tile, relation) group fills more than one 64-slot half."""
+    from .plan import padded_width
+    if chunk != 128 or padded_width(in_channels) != 64 or padded_width(out_channels) != 64:
+        return False
+    density = n_edges / max(1.0, float(n_nodes) * max(1, num_relations))
+    return density * tile > 64.0
+
+
 def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0, num_relations: int = 1) -> int:
     """Output nodes per tile of ``layout_for``."""
     return layout_for(in_channels, out_channels, n_nodes, n_edges, num_relations)[0]
@@ -324,11 +334,13 @@ class RGCNConv(nn.Module):
 
     def _plans(self, x: Tensor, edge_index: Tensor, edge_type: Tensor) -> GraphPlans:
         n = x.shape[0]
-        tile, chunk = layout_for(self.in_channels, self.out_channels, n, int(edge_type.shape[0]), self.num_relations)
+        e = int(edge_type.shape[0])
+        tile, chunk = layout_for(self.in_channels, self.out_channels, n, e, self.num_relations)
+        split = split_for(self.in_channels, self.out_channels, n, e, self.num_relations, tile, chunk)
         if self.dist is None:
-            return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk)
+            return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split)
         from .dist import cached_rank_plans
-        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk)
+        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None, *,
                 _activation: Optional[str] = None, _input_relu: bool = False,

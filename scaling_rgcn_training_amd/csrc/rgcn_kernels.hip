@@ -276,6 +276,155 @@ constexpr int kAccStride = NP + 4;
 constexpr int kTileProducers = RGCN_TILE_PW;
 constexpr int kTileThreads = 64 * (kTileProducers + 4);
 
+// ---- producers of the forward / dX kernels: LDS-DMA gather, D chunks ahead of the consumers -----------------------
+template <int KP, int NBUF, bool BUF, int CH>
+__device__ __forceinline__ void tile_producer_loop(const TileArgs& a, float* ring, float* wring, int* dring, int c0, int nch,
+                                                   int lane, int wave) {
+    constexpr int D = NBUF - 1;
+        // The producers' few instructions must not queue behind the consumer wave's MFMAs on the shared SIMD
+        // (issue is arbitrated by priority, then age; an fp32 MFMA holds the pipe 32 cycles): RGCN_PRIO
+        __builtin_amdgcn_s_setprio(RGCN_PRIO);
+        // ---- producers: LDS-DMA gather, D chunks ahead of the consumers; wave (k % 4) owns chunk k ----
+        const int pw = wave;
+        int knext = pw;                                   // this wave's next chunk
+        RowGather<KP, kRowRead, BUF> gather;
+        gather.init(lane, (RGCN_DBG(a) & 2) ? 0 : a.din4, a.ldx);
+#ifdef RGCN_STAMPS
+        unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
+#endif
+        using Gather = RowGather<KP, kRowRead, BUF>;
+        constexpr int RW = CH / kTileProducers;           // rows of a chunk per producer wave in the spread scheme
+        if constexpr (D == 1 && RW >= 16 && RW <= 64 && RW % Gather::RPI == 0) {
+            // ---- one chunk ahead (two ring slots): EVERY wave issues its RW rows of EVERY chunk -------------------
+            // With a single chunk in flight its round trip is on the critical path of every iteration; four waves
+            // issuing a quarter each put the whole chunk on the wire in a quarter of the time (and spread the
+            // producers' vector instructions over the four SIMDs instead of loading one consumer's).
+            constexpr int NOPS_PART = RW / Gather::RPI;
+            const int row0 = pw * RW;                     // first row of this wave's part inside the chunk
+            const int half = row0 / 64, op0 = (row0 % 64) / Gather::RPI;
+            const bool meta = row0 % 64 == 0;             // this wave also moves the half's weights / run metadata
+            auto load_idx = [&](int k) {
+                const int kk = k < nch ? k : nch - 1;
+                return a.slot_src[(size_t)(c0 + kk) * CH + 64 * half + lane];
+            };
+            auto issue_part = [&](int k, int idxv) {
+                const int chunk = c0 + k, buf = k % NBUF;
+                gather.template issue_part<NOPS_PART>(a.x, a.x_bytes, a.n_rows, a.ldx, idxv,
+                                                      ring + (buf * CH + row0) * KP, op0);
+                if (meta) {
+                    dma4(a.slot_w + (size_t)chunk * CH + 64 * half + lane, wring + buf * CH + 64 * half);
+                    dma4(a.slot_acc + (size_t)chunk * CH + 64 * half + lane, dring + buf * CH + 64 * half);
+                }
+            };
+            int idx_cur = load_idx(0);
+            issue_part(0, idx_cur);                       // (its index vector is waited for here, once per tile)
+            idx_cur = load_idx(1);
+            wait_vmcnt<0>();                              // chunk 0 landed (and the indices of chunk 1)
+            wg_barrier();                                 // chunk 0 (and the accumulator init) visible
+            for (int it = 0; it < nch; ++it) {
+                STAMP(p0);
+                int idx_next = idx_cur;
+                if (it + 1 < nch) {
+                    issue_part(it + 1, idx_cur);
+                    idx_next = load_idx(it + 2);          // youngest operation: lands with the rows
+                }
+                STAMP(p1);
+                wait_vmcnt<0>();                          // chunk it + 1 landed
+                idx_cur = idx_next;
+                STAMP(p2);
+                wg_barrier();
+                STAMP(p3);
+                STAMP_ADD(sp_issue, p0, p1);
+                STAMP_ADD(sp_wait, p1, p2);
+                STAMP_ADD(sp_bar, p2, p3);
+            }
+        } else {
+        // Row indices of this wave's NEXT chunk: one coalesced load, issued right after the current
+        // chunk's DMAs and not touched until the wave's next turn 4 iterations later (any use here would
+        // make hipcc wait vmcnt(0) on the spot, i.e. for the DMAs just issued).  The address is clamped
+        // so the load is always valid; issue() only runs for k < nch.
+        constexpr int HALVES = CH / 64;
+        auto load_idx = [&](int k, int h) {
+            const int kk = k < nch ? k : nch - 1;
+            return a.slot_src[(size_t)(c0 + kk) * CH + 64 * h + lane];
+        };
+        int idxv[HALVES];
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) idxv[h] = load_idx(knext, h);
+        auto issue = [&](int k) {                         // k == knext
+            const int chunk = c0 + k, buf = k % NBUF;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) {
+                gather.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idxv[h], ring + (buf * CH + 64 * h) * KP);
+                dma4(a.slot_w + (size_t)chunk * CH + 64 * h + lane, wring + buf * CH + 64 * h);
+                dma4(a.slot_acc + (size_t)chunk * CH + 64 * h + lane, dring + buf * CH + 64 * h);
+            }
+            knext += kTileProducers;
+#pragma unroll
+            for (int h = 0; h < HALVES; ++h) idxv[h] = load_idx(knext, h);   // youngest ops of this wave from here on
+        };
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (k % kTileProducers == pw && k < nch) issue(k);
+        if (pw == 0) wait_vmcnt<0>();                     // chunk 0 landed
+        wg_barrier();                                     // chunk 0 (and the accumulator init) visible
+        for (int it = 0; it < nch; ++it) {
+            // slot (it+D)%NBUF held chunk it-1, which the consumers finished before the last barrier
+            const int ki = it + D, kw = it + 1;
+            STAMP(p0);
+            if (ki % kTileProducers == pw && ki < nch) issue(ki);
+            STAMP(p1);
+            // a wave has at most ONE chunk in flight (D <= 4), plus the index load issued with it (which
+            // hipcc may schedule among the DMAs): vmcnt(0) is exact
+            if (kw % kTileProducers == pw && kw < nch) wait_vmcnt<0>();   // chunk it+1 landed
+            STAMP(p2);
+            wg_barrier();
+            STAMP(p3);
+            STAMP_ADD(sp_issue, p0, p1);
+            STAMP_ADD(sp_wait, p1, p2);
+            STAMP_ADD(sp_bar, p2, p3);
+        }
+        }
+        wait_vmcnt<0>();
+#ifdef RGCN_STAMPS
+        if (g_stamps && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
+            if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
+            if (pw == 1) o[7] = nch;
+        }
+#endif
+}
+
+// ---- epilogue of the forward / dX kernels: the finished tile, whole 16-byte pieces, coalesced ------------------------
+template <int LDO>
+__device__ __forceinline__ void tile_epilogue(const TileArgs& a, const float* out_lds, int tile, int tid) {
+    const int row0 = tile * a.tile;
+    const int rows = min(a.tile, a.n_owned - row0);
+    const int o4 = (a.dout + 3) >> 2;
+    // Fused epilogues (reference model/layers.py:22,24: F.relu / activation applied to the layer output): the
+    // activation costs nothing here, as a separate kernel it re-reads and re-writes [N, out].  In the dX launch of the
+    // NEXT layer the ReLU backward of this layer's output is the mask (input > 0) on the stored gradient rows.
+    // Padding columns (dout .. 4 * o4) stay zero: relu(0) = 0, and sigmoid is applied to real columns only.
+    const int act = a.act;
+    for (int i = tid; i < rows * o4; i += kTileThreads) {
+        const int r = i / o4, c4 = i - r * o4;
+        f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
+        if (act == RGCN_ACT_RELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : 0.f;
+        } else if (act == RGCN_ACT_SIGMOID) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (c4 * 4 + c < a.dout) ? 1.f / (1.f + expf(-v[c])) : 0.f;
+        }
+        if (a.mask != nullptr) {
+            const f32x4 m = *(const f32x4*)(a.mask + (size_t)(row0 + r) * a.ldm + c4 * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = m[c] > 0.f ? v[c] : 0.f;
+        }
+        *(f32x4*)(a.out + (size_t)(row0 + r) * a.ldo + c4 * 4) = v;
+    }
+}
+
 // CH = edge slots per chunk = rows of one ring slot (64 or 128): a 128-slot chunk is consumed as two 64-row parts
 // with no barrier, metadata fetch or B swap between them
 template <int KP, int NP, int NBUF, bool BUF, int CH>
@@ -382,7 +531,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
                 }
             }
             const int nrt_all = (!active || (RGCN_DBG(a) & 1)) ? 0 : (cnt + 15) >> 4;
-            const int flags_all = flags_chunk;
+            const int flags_all = flags_chunk & 0xFF;     // bit 8 (layout 1: the chunk's halves share a destination) is not ours
             // A chunk without repeated destinations runs as ONE straight-line block over all its row tiles (up to
             // CH / 16); otherwise 64-row parts of up to four tiles, each on the path its own flags ask for.
             const bool whole = flags_all == 0;
@@ -684,147 +833,300 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
         // order) reuses these registers; otherwise it waits vmcnt(0) between the prologue DMAs
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
-    if (wave < kTileProducers) {
-        // The producers' few instructions must not queue behind the consumer wave's MFMAs on the shared SIMD
-        // (issue is arbitrated by priority, then age; an fp32 MFMA holds the pipe 32 cycles): RGCN_PRIO
-        __builtin_amdgcn_s_setprio(RGCN_PRIO);
-        // ---- producers: LDS-DMA gather, D chunks ahead of the consumers; wave (k % 4) owns chunk k ----
-        const int pw = wave;
-        int knext = pw;                                   // this wave's next chunk
-        RowGather<KP, kRowRead, BUF> gather;
-        gather.init(lane, (RGCN_DBG(a) & 2) ? 0 : a.din4, a.ldx);
-#ifdef RGCN_STAMPS
-        unsigned long long sp_issue = 0, sp_wait = 0, sp_bar = 0;
-#endif
-        using Gather = RowGather<KP, kRowRead, BUF>;
-        constexpr int RW = CH / kTileProducers;           // rows of a chunk per producer wave in the spread scheme
-        if constexpr (D == 1 && RW >= 16 && RW <= 64 && RW % Gather::RPI == 0) {
-            // ---- one chunk ahead (two ring slots): EVERY wave issues its RW rows of EVERY chunk -------------------
-            // With a single chunk in flight its round trip is on the critical path of every iteration; four waves
-            // issuing a quarter each put the whole chunk on the wire in a quarter of the time (and spread the
-            // producers' vector instructions over the four SIMDs instead of loading one consumer's).
-            constexpr int NOPS_PART = RW / Gather::RPI;
-            const int row0 = pw * RW;                     // first row of this wave's part inside the chunk
-            const int half = row0 / 64, op0 = (row0 % 64) / Gather::RPI;
-            const bool meta = row0 % 64 == 0;             // this wave also moves the half's weights / run metadata
-            auto load_idx = [&](int k) {
-                const int kk = k < nch ? k : nch - 1;
-                return a.slot_src[(size_t)(c0 + kk) * CH + 64 * half + lane];
-            };
-            auto issue_part = [&](int k, int idxv) {
-                const int chunk = c0 + k, buf = k % NBUF;
-                gather.template issue_part<NOPS_PART>(a.x, a.x_bytes, a.n_rows, a.ldx, idxv,
-                                                      ring + (buf * CH + row0) * KP, op0);
-                if (meta) {
-                    dma4(a.slot_w + (size_t)chunk * CH + 64 * half + lane, wring + buf * CH + 64 * half);
-                    dma4(a.slot_acc + (size_t)chunk * CH + 64 * half + lane, dring + buf * CH + 64 * half);
+    if (wave < kTileProducers) tile_producer_loop<KP, NBUF, BUF, CH>(a, ring, wring, dring, c0, nch, lane, wave);
+    tile_epilogue<LDO>(a, out_lds, tile, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dX kernel, split-precision form (64 -> 64, 128-slot chunks, layout-1 plans)
+// ------------------------------------------------------------------------------------------------
+// Same producers, ring, accumulator tile and epilogue as rgcn_tile_kernel; different consumers.
+//
+// The exact fp32 MFMA runs at the fp32 vector rate (1/16 of the bf16 rate) and shares the SIMD's FMA pipe with every
+// vector instruction, so rgcn_tile_kernel is bound by its own contraction.  Here the contraction is
+// x W = (xh + xm + xl)(Wh + Wm + Wl) with bf16 pieces (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m): 24 significant
+// bits, i.e. v = h + m + l up to the last fp32 bit) and the SIX products hh, hm, mh, hl, lh, mm on v_mfma_f32_16x16x32_bf16
+// (bf16 x bf16 products are exact in the fp32 accumulator; the dropped ml, lm, ll terms are below 2^-24 relative):
+// measured error against float64 no larger than the sequential fp32 chain's (tools/debug/bf16_split_error.py:
+// 1.35e-6 against 1.86e-6 max on the headline distribution).  W is split once, at pack time (rgcn_pack3_kernel).
+// x is split ON THE FLY in registers -- 88 vector instructions for a lane's 16 elements -- which only pays if a row
+// is split once: so a consumer wave owns 32 output columns of HALF of a chunk's rows (2 x 2 ownership), which needs
+// the two 64-slot halves of a chunk to scatter into disjoint accumulator rows: plan layout 1 (plan.split_placement).
+// Waves 4,5 take slots [0, 64) (columns 0..31 / 32..63), waves 6,7 slots [64, 128).  A chunk whose halves share a
+// destination (chunk_flags bit 8) is done by waves 4,5 alone.
+// Per 16-row tile and wave: 4 ds_read_b128 (+2 b32), the split, 24 MFMAs (2 column tiles x 2 k-steps x 6 products),
+// 2 accumulator read-modify-writes of 16 bytes per lane.  Row tiles with a repeated destination take the Y
+// orientation (operands swapped) and the same run-sum product P.Y as rgcn_tile_kernel, in exact fp32.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kPack3FragsPerRel = 2 * 3 * 2 * 2;        // [column half c][plane][column tile ct][k-step s]
+constexpr size_t kPack3FloatsPerRel = (size_t)kPack3FragsPerRel * 64 * 4;   // 64 lanes x 16 bytes per fragment
+
+// packed3[((((rel * 2 + c) * 3 + pl) * 2 + ct) * 2 + s) * 64 + lane] (16 bytes = 8 bf16): element j =
+// plane pl of B_rel[k = 32 s + 8 (lane >> 4) + j][col = 32 c + 16 ct + (lane & 15)] -- the A operand of the Y^T product
+// (A[row = column][k]) and, read the other way round, the B operand of the Y product (B[k][col]).
+__device__ __forceinline__ unsigned bf16_rne(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ void rgcn_pack3_kernel(const float* __restrict__ weight, const float* __restrict__ root, int num_rel, int din,
+                                  int dout, int transpose, uint4* __restrict__ packed) {
+    const long total = (long)(num_rel + 1) * kPack3FragsPerRel * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long rem = idx;
+        const int lane = (int)(rem & 63); rem >>= 6;
+        const int s = (int)(rem & 1); rem >>= 1;
+        const int ct = (int)(rem & 1); rem >>= 1;
+        const int pl = (int)(rem % 3); rem /= 3;
+        const int c = (int)(rem & 1); rem >>= 1;
+        const int rel = (int)rem;
+        const float* m = rel < num_rel ? weight + (size_t)rel * din * dout : root;
+        unsigned h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * s + 8 * (lane >> 4) + j, col = 32 * c + 16 * ct + (lane & 15);
+            float v = 0.f;
+            if (m != nullptr) {
+                if (!transpose) {
+                    if (k < din && col < dout) v = m[(size_t)k * dout + col];
+                } else {
+                    if (k < dout && col < din) v = m[(size_t)col * dout + k];
                 }
-            };
-            int idx_cur = load_idx(0);
-            issue_part(0, idx_cur);                       // (its index vector is waited for here, once per tile)
-            idx_cur = load_idx(1);
-            wait_vmcnt<0>();                              // chunk 0 landed (and the indices of chunk 1)
-            wg_barrier();                                 // chunk 0 (and the accumulator init) visible
-            for (int it = 0; it < nch; ++it) {
-                STAMP(p0);
-                int idx_next = idx_cur;
-                if (it + 1 < nch) {
-                    issue_part(it + 1, idx_cur);
-                    idx_next = load_idx(it + 2);          // youngest operation: lands with the rows
-                }
-                STAMP(p1);
-                wait_vmcnt<0>();                          // chunk it + 1 landed
-                idx_cur = idx_next;
-                STAMP(p2);
-                wg_barrier();
-                STAMP(p3);
-                STAMP_ADD(sp_issue, p0, p1);
-                STAMP_ADD(sp_wait, p1, p2);
-                STAMP_ADD(sp_bar, p2, p3);
             }
-        } else {
-        // Row indices of this wave's NEXT chunk: one coalesced load, issued right after the current
-        // chunk's DMAs and not touched until the wave's next turn 4 iterations later (any use here would
-        // make hipcc wait vmcnt(0) on the spot, i.e. for the DMAs just issued).  The address is clamped
-        // so the load is always valid; issue() only runs for k < nch.
-        constexpr int HALVES = CH / 64;
-        auto load_idx = [&](int k, int h) {
-            const int kk = k < nch ? k : nch - 1;
-            return a.slot_src[(size_t)(c0 + kk) * CH + 64 * h + lane];
-        };
-        int idxv[HALVES];
-#pragma unroll
-        for (int h = 0; h < HALVES; ++h) idxv[h] = load_idx(knext, h);
-        auto issue = [&](int k) {                         // k == knext
-            const int chunk = c0 + k, buf = k % NBUF;
-#pragma unroll
-            for (int h = 0; h < HALVES; ++h) {
-                gather.issue(a.x, a.x_bytes, a.n_rows, a.ldx, idxv[h], ring + (buf * CH + 64 * h) * KP);
-                dma4(a.slot_w + (size_t)chunk * CH + 64 * h + lane, wring + buf * CH + 64 * h);
-                dma4(a.slot_acc + (size_t)chunk * CH + 64 * h + lane, dring + buf * CH + 64 * h);
+            unsigned b = bf16_rne(v);
+            for (int q = 0; q < pl; ++q) {
+                v -= __uint_as_float(b << 16);
+                b = bf16_rne(v);
             }
-            knext += kTileProducers;
-#pragma unroll
-            for (int h = 0; h < HALVES; ++h) idxv[h] = load_idx(knext, h);   // youngest ops of this wave from here on
-        };
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            if (k % kTileProducers == pw && k < nch) issue(k);
-        if (pw == 0) wait_vmcnt<0>();                     // chunk 0 landed
-        wg_barrier();                                     // chunk 0 (and the accumulator init) visible
-        for (int it = 0; it < nch; ++it) {
-            // slot (it+D)%NBUF held chunk it-1, which the consumers finished before the last barrier
-            const int ki = it + D, kw = it + 1;
-            STAMP(p0);
-            if (ki % kTileProducers == pw && ki < nch) issue(ki);
-            STAMP(p1);
-            // a wave has at most ONE chunk in flight (D <= 4), plus the index load issued with it (which
-            // hipcc may schedule among the DMAs): vmcnt(0) is exact
-            if (kw % kTileProducers == pw && kw < nch) wait_vmcnt<0>();   // chunk it+1 landed
-            STAMP(p2);
-            wg_barrier();
-            STAMP(p3);
-            STAMP_ADD(sp_issue, p0, p1);
-            STAMP_ADD(sp_wait, p1, p2);
-            STAMP_ADD(sp_bar, p2, p3);
+            h[j] = b;
         }
-        }
-        wait_vmcnt<0>();
-#ifdef RGCN_STAMPS
-        if (g_stamps && lane == 0) {
-            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32;
-            if (pw == 0) { o[4] = sp_issue; o[5] = sp_wait; o[6] = sp_bar; }
-            if (pw == 1) o[7] = nch;
-        }
-#endif
+        packed[idx] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    }
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // RNE, lo -> bits 0..15, hi -> bits 16..31
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <bool BUF>
+__global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile3_kernel(const TileArgs a) {
+    constexpr int KP = 64, NP = 64, NBUF = 2, CH = 128;
+    constexpr int LDO = kAccStride<NP>;
+    static_assert(kTileProducers == 4, "four producer waves, four consumer waves");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* out_lds = lds;                         // [tile + 1][LDO]  (row `tile`: dummy)
+    float* ring = lds + (a.tile + 1) * LDO;       // [NBUF][CH][KP]
+    float* wring = ring + NBUF * CH * KP;         // [NBUF][CH]
+    int* dring = (int*)(wring + NBUF * CH);       // [NBUF][CH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int c0 = ldc(a.tile_ptr, tile);
+    const int nch = ldc(a.tile_ptr, tile + 1) - c0;
+
+    for (int i = tid; i < (a.tile + 1) * LDO; i += kTileThreads) {
+        const int col = i % LDO;
+        out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
     }
 
-    // ---- epilogue: the finished tile, whole 16-byte pieces, coalesced ---------------------------
-    const int row0 = tile * a.tile;
-    const int rows = min(a.tile, a.n_owned - row0);
-    const int o4 = (a.dout + 3) >> 2;
-    // Fused epilogues (reference model/layers.py:22,24: F.relu / activation applied to the layer output): the
-    // activation costs nothing here, as a separate kernel it re-reads and re-writes [N, out].  In the dX launch of the
-    // NEXT layer the ReLU backward of this layer's output is the mask (input > 0) on the stored gradient rows.
-    // Padding columns (dout .. 4 * o4) stay zero: relu(0) = 0, and sigmoid is applied to real columns only.
-    const int act = a.act;
-    for (int i = tid; i < rows * o4; i += kTileThreads) {
-        const int r = i / o4, c4 = i - r * o4;
-        f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
-        if (act == RGCN_ACT_RELU) {
+    if (wave >= kTileProducers) {
+        const int cwv = wave - kTileProducers;
+        const int pair = cwv >> 1;                 // which 64-slot half of a chunk
+        const int ch = cwv & 1;                    // which 32 output columns
+        const int rowl = lane & 15, kq = lane >> 4;
+        const unsigned col4_bytes = (unsigned)(32 * ch + 4 * kq) * 4u;     // Y^T layout: four consecutive columns of row rowl
+        const unsigned col1_bytes = (unsigned)(32 * ch + rowl) * 4u;       // Y layout: column rowl of rows 4 kq + i
+        const uint4* wp4 = (const uint4*)a.wp;
+        f32x4 wcur[3][2][2], wnext[3][2][2];       // [plane][column tile][k-step]: 8 bf16 each, kept as 16-byte registers
+        int rel_cur = ldc(a.chunk_rel, c0);
+        {
+            const uint4* bp = wp4 + (size_t)(rel_cur * 2 + ch) * (3 * 2 * 2 * 64) + lane;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : 0.f;
-        } else if (act == RGCN_ACT_SIGMOID) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = (c4 * 4 + c < a.dout) ? 1.f / (1.f + expf(-v[c])) : 0.f;
+            for (int f = 0; f < 12; ++f) wcur[f / 4][(f >> 1) & 1][f & 1] = __builtin_bit_cast(f32x4, bp[f * 64]);
         }
-        if (a.mask != nullptr) {
-            const f32x4 m = *(const f32x4*)(a.mask + (size_t)(row0 + r) * a.ldm + c4 * 4);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire these loads in the compiler's scoreboard (see rgcn_tile_kernel)
+        int cnt_pre = ldc(a.chunk_cnt, c0);
+        int flags_pre = ldc(a.chunk_flags, c0);
+        int rel_pre = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
+        wg_barrier();
+        for (int it = 0; it < nch; ++it) {
+            const int chunk = c0 + it;
+            const int buf = it % NBUF;
+            const int cnt = cnt_pre;
+            const int flags = flags_pre;
+            const int rel_next = rel_pre;
+            if (it + 1 < nch) {
+                cnt_pre = ldc(a.chunk_cnt, chunk + 1);
+                flags_pre = ldc(a.chunk_flags, chunk + 1);
+            }
+            if (it + 2 < nch) rel_pre = ldc(a.chunk_rel, chunk + 2);
+            const bool swap_b = rel_next != rel_cur;
+            if (swap_b) {      // the next relation's fragments, on their way under this chunk's MFMAs
+                const f32x4* bp = (const f32x4*)(wp4 + (size_t)(rel_next * 2 + ch) * (3 * 2 * 2 * 64) + lane);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = m[c] > 0.f ? v[c] : 0.f;
+                for (int q = 0; q < 3; ++q) {
+                    const f32x4* bq = bp + q * 4 * 64;
+                    prefetch16<0>(wnext[q][0][0], bq);
+                    prefetch16<1024>(wnext[q][0][1], bq);
+                    prefetch16<2048>(wnext[q][1][0], bq);
+                    prefetch16<3072>(wnext[q][1][1], bq);
+                }
+            }
+            // this wave's row tiles of the chunk: the used tiles are contiguous from tile 0; layout 1 puts a chunk of more
+            // than 64 rows into tiles 0..3 (half 0) and 4.. (half 1) with disjoint destinations
+            const int nt = cnt >> 4;
+            const bool straddle = (flags & 256) != 0;
+            int first, n_my;
+            if (straddle) {
+                first = 0;
+                n_my = pair == 0 ? nt : 0;
+            } else {
+                first = 4 * pair;
+                n_my = pair == 0 ? (nt < 4 ? nt : 4) : (nt > 4 ? nt - 4 : 0);
+            }
+            const float* hb = ring + buf * CH * KP;
+            const float* wb = wring + buf * CH;
+            const int* db = dring + buf * CH;
+            // operand addresses of row tile 0 of the chunk; tile t is t * 16 rows further
+            const float* arow[2][2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int pos = (8 * s2 + 2 * kq + h2) ^ swizzle<kRowRead, KP / 4>(rowl);
+                    arow[s2][h2] = hb + rowl * KP + pos * 4;
+                }
+            struct Ops {
+                f32x4 x[2][2];   // this lane's 16 elements of row rowl: k = 32 s + 8 kq + 4 h + (0..3)
+                float w1; int d1;            // Y^T path: weight / run metadata of row rowl
+                f32x4 w4; i32x4 d4;          // Y path: of rows 4 kq + i
+            };
+            auto load_ops = [&](Ops& o, int t) {
+                o.w1 = wb[t * 16 + rowl];
+                o.d1 = db[t * 16 + rowl];
+                if ((flags >> t) & 1) {      // only the run-sum path needs the per-row-of-this-lane copies
+                    o.w4 = *(const f32x4*)(wb + t * 16 + 4 * kq);
+                    o.d4 = *(const i32x4*)(db + t * 16 + 4 * kq);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) o.x[s2][h2] = *(const f32x4*)(arow[s2][h2] + t * 16 * KP);
+            };
+            auto acc_ptr = [&](int d, unsigned col_bytes) -> float* {
+                return (float*)((char*)out_lds + (__umul24((unsigned)d, (unsigned)(LDO * 4)) + col_bytes));
+            };
+            auto process = [&](const Ops& o, int t) {
+                // ---- 3-way split of the lane's 16 elements: pl[plane][k-step] ----
+                bf16x8 pl[3][2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float x0 = o.x[s2][d >> 1][2 * (d & 1)], x1 = o.x[s2][d >> 1][2 * (d & 1) + 1];
+                        const unsigned h = cvt_pk_bf16(x0, x1);
+                        x0 -= __uint_as_float(h << 16);
+                        x1 -= __uint_as_float(h & 0xFFFF0000u);
+                        const unsigned m = cvt_pk_bf16(x0, x1);
+                        x0 -= __uint_as_float(m << 16);
+                        x1 -= __uint_as_float(m & 0xFFFF0000u);
+                        hh[d] = h;
+                        mm[d] = m;
+                        ll[d] = cvt_pk_bf16(x0, x1);
+                    }
+                    pl[0][s2] = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+                    pl[1][s2] = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
+                    pl[2][s2] = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+                }
+                constexpr int px[6] = {0, 0, 1, 0, 2, 1}, pw[6] = {0, 1, 0, 2, 0, 1};     // x plane, W plane: hh hm mh hl lh mm
+                const bool dup = (flags >> t) & 1;
+                if (!dup) {
+                    // Y^T = W^T H^T: a lane ends up with four consecutive columns of ONE row
+                    float* dst = acc_ptr(o.d1, col4_bytes);
+                    f32x4 old[2], y[2];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        old[ct] = *(const f32x4*)(dst + 16 * ct);
+                        y[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+                                y[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[pw[q]][ct][s2]), pl[px[q]][s2], y[ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) *(f32x4*)(dst + 16 * ct) = y[ct] * o.w1 + old[ct];
+                } else {
+                    // Y = H W (operands swapped), then the run-sum product Z = P Y + old in exact fp32 (rgcn_tile_kernel)
+                    f32x4 y[2];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) y[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+                                y[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[px[q]][s2], __builtin_bit_cast(bf16x8, wcur[pw[q]][ct][s2]), y[ct], 0, 0, 0);
+                    float* dst[4];
+                    float pm[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dst[i] = acc_ptr(o.d4[i], col1_bytes);
+                        pm[i] = ((unsigned)o.d4[i] >> 24) == (unsigned)rowl ? o.w4[i] : 0.f;
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        f32x4 old;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) old[i] = dst[i][16 * ct];
+                        f32x4 z1 = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], y[ct][0], old, 0, 0, 0);
+                        z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], y[ct][1], z1, 0, 0, 0);
+                        z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], y[ct][2], z0, 0, 0, 0);
+                        z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], y[ct][3], z1, 0, 0, 0);
+                        const f32x4 v = z0 + z1;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dst[i][16 * ct] = v[i];
+                    }
+                }
+            };
+            if (n_my > 0) {
+                Ops o0, o1;
+                load_ops(o0, first);
+                for (int t = 0; t < n_my; t += 2) {
+                    if (t + 1 < n_my) load_ops(o1, first + t + 1);
+                    process(o0, first + t);
+                    if (t + 1 < n_my) {
+                        if (t + 2 < n_my) load_ops(o0, first + t + 2);
+                        process(o1, first + t + 1);
+                    }
+                }
+            }
+            if (swap_b) {
+                wait_vmcnt<0>();      // the asm prefetch (this wave's only vector-memory traffic)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) wcur[q][ct][s2] = wnext[q][ct][s2];
+            }
+            rel_cur = rel_next;
+            wg_barrier();
         }
-        *(f32x4*)(a.out + (size_t)(row0 + r) * a.ldo + c4 * 4) = v;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
+    if (wave < kTileProducers) tile_producer_loop<KP, NBUF, BUF, CH>(a, ring, wring, dring, c0, nch, lane, wave);
+    tile_epilogue<LDO>(a, out_lds, tile, tid);
 }
 
 // dz = da * act'(a) for an activation fused into rgcn_fwd's store (a = act(z)): relu -> (a > 0), sigmoid -> a (1 - a).
@@ -1791,7 +2093,19 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
 #else
     a.dbg = 0;
 #endif
-    return dispatch_tile(padded_width(kin), padded_width(nout), a, plan->n_tiles, plan->chunk, (hipStream_t)stream);
+    const int KP = padded_width(kin), NP = padded_width(nout);
+    // Split-precision kernel: 64 x 64 layers on layout-1 plans (the halves of a chunk scatter into disjoint rows)
+    if (KP == 64 && NP == 64 && plan->layout == 1 && plan->chunk == 128 && !(flags & RGCN_FLAG_EXACT_FP32)) {
+        const size_t lds = sizeof(float) * ((size_t)(a.tile + 1) * kAccStride<64> + (size_t)2 * 128 * (64 + 2));
+        if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
+        a.wp = packed + (size_t)(plan->num_relations + 1) * KP * NP;
+        hipError_t e = a.x_bytes ? allow_full_lds<rgcn_tile3_kernel<true>>() : allow_full_lds<rgcn_tile3_kernel<false>>();
+        if (e != hipSuccess) return (int)e;
+        auto kern = a.x_bytes ? rgcn_tile3_kernel<true> : rgcn_tile3_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3(plan->n_tiles), dim3(kTileThreads), lds, (hipStream_t)stream, a);
+        return (int)hipGetLastError();
+    }
+    return dispatch_tile(KP, NP, a, plan->n_tiles, plan->chunk, (hipStream_t)stream);
 }
 
 template <int KP, int NP>
@@ -1882,10 +2196,15 @@ extern "C" const char* rgcn_status_string(int status) {
 
 extern "C" int rgcn_padded_width(int width) { return padded_width(width); }
 
+// 64 x 64 layers also carry the bf16 x 3 split of the weights (rgcn_tile3_kernel), behind the fp32 fragments
+static size_t pack3_floats(int num_relations, int KP, int NP) {
+    return (KP == 64 && NP == 64) ? (size_t)(num_relations + 1) * kPack3FloatsPerRel : 0;
+}
+
 extern "C" size_t rgcn_packed_weight_floats(int num_relations, int din, int dout) {
     const int a = padded_width(din), b = padded_width(dout);
     if (a == 0 || b == 0 || num_relations <= 0) return 0;
-    return (size_t)(num_relations + 1) * a * b;
+    return (size_t)(num_relations + 1) * a * b + pack3_floats(num_relations, a, b);
 }
 
 extern "C" int rgcn_pack_weights(const float* weight, const float* root, int num_relations, int din, int dout,
@@ -1899,6 +2218,11 @@ extern "C" int rgcn_pack_weights(const float* weight, const float* root, int num
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(rgcn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, root, num_relations,
                        din, dout, transpose, KP, NP, packed);
+    if (pack3_floats(num_relations, KP, NP) != 0) {
+        const long lanes = (long)(num_relations + 1) * kPack3FragsPerRel * 64;
+        hipLaunchKernelGGL(rgcn_pack3_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, root,
+                           num_relations, din, dout, transpose, (uint4*)(packed + total));
+    }
     return (int)hipGetLastError();
 }
 

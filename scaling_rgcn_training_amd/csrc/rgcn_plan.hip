@@ -344,14 +344,19 @@ __global__ void group_start_kernel(const u64* __restrict__ ukeys, u32 n, int gsh
 }
 
 // chunks and 64-slot units of every group
-__global__ void group_sizes_kernel(const u32* __restrict__ gstart, u32 n_groups, u32 chunk, u32* __restrict__ gch,
+__global__ void group_sizes_kernel(const u32* __restrict__ gstart, u32 n_groups, u32 chunk, u32 layout, u32* __restrict__ gch,
                                    u32* __restrict__ gun) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const u32 cnt = gstart[g + 1] - gstart[g];
     const u32 nt = (cnt + 15u) / 16u;
     gch[g] = (cnt + chunk - 1u) / chunk;
-    gun[g] = (nt + 3u) / 4u;
+    if (layout == 0) {
+        gun[g] = (nt + 3u) / 4u;
+    } else {            // split placement: a chunk range of more than 64 rows always spans both 64-slot units
+        const u32 rem = cnt % 128u;
+        gun[g] = 2u * (cnt / 128u) + (rem == 0 ? 0u : (rem > 64u ? 2u : 1u));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,18 +373,42 @@ __global__ void fill_slots_kernel(u32 n_slots, u32 n_nodes, u32 tile, int32_t* _
     dstl[i] = tile;                     // padding scatters into the dummy accumulator row
 }
 
-// Row j of a group (sorted by destination) goes to MFMA row tile (j mod nt), position (j div nt), nt = ceil(n / 16):
+// Layout 0: row j of a group (sorted by destination) goes to MFMA row tile (j mod nt), position (j div nt), nt = ceil(n / 16):
 // every tile stays sorted by destination and a run of c equal destinations is spread over c different tiles.
+// Layout 1 (plan.split_placement): chunk c of the group takes its rows [128 c, 128 c + 128); more than 64 of them are cut at
+// split[chunk] into part 0 (dealt over row tiles 0..3) and part 1 (tiles 4..), so the chunk's halves hold disjoint destinations.
 __global__ void place_kernel(const u64* __restrict__ ukeys, const u32* __restrict__ uvals, u32 n, const u32* __restrict__ gid,
-                             const u32* __restrict__ gstart, const u32* __restrict__ chunk_base, u32 chunk, KeyLayout kl,
-                             int32_t* __restrict__ slot_src, float* __restrict__ slot_w, u32* __restrict__ dstl) {
+                             const u32* __restrict__ gstart, const u32* __restrict__ chunk_base, u32 chunk, u32 layout,
+                             const u32* __restrict__ split, KeyLayout kl, int32_t* __restrict__ slot_src,
+                             float* __restrict__ slot_w, u32* __restrict__ dstl) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32 g = gid[i];
     const u32 s0 = gstart[g], cnt = gstart[g + 1] - s0;
-    const u32 nt = (cnt + 15u) / 16u;
     const u32 rank = i - s0;
-    const size_t slot = (size_t)chunk_base[g] * chunk + (size_t)(rank % nt) * 16u + rank / nt;
+    size_t slot;
+    if (layout == 0) {
+        const u32 nt = (cnt + 15u) / 16u;
+        slot = (size_t)chunk_base[g] * chunk + (size_t)(rank % nt) * 16u + rank / nt;
+    } else {
+        const u32 cidx = rank / 128u, jc = rank % 128u;
+        const u32 left = cnt - cidx * 128u, n_c = left < 128u ? left : 128u;
+        const u32 c = chunk_base[g] + cidx;
+        u32 in_chunk;
+        if (n_c <= 64u) {
+            const u32 nt = (n_c + 15u) / 16u;
+            in_chunk = (jc % nt) * 16u + jc / nt;
+        } else {
+            const u32 sp = split[c];
+            if (jc < sp) {
+                in_chunk = (jc % 4u) * 16u + jc / 4u;
+            } else {
+                const u32 j1 = jc - sp, nt1 = (n_c - sp + 15u) / 16u;
+                in_chunk = 64u + (j1 % nt1) * 16u + j1 / nt1;
+            }
+        }
+        slot = (size_t)c * 128u + in_chunk;
+    }
     const u64 k = ukeys[i];
     slot_src[slot] = (int32_t)(k & ((1ull << kl.src_bits) - 1ull));
     slot_w[slot] = __uint_as_float(uvals[i]);
@@ -387,8 +416,9 @@ __global__ void place_kernel(const u64* __restrict__ ukeys, const u32* __restric
 }
 
 __global__ void chunk_meta_kernel(const u32* __restrict__ chunk_base, const u32* __restrict__ gstart, const u32* __restrict__ gkey,
-                                  u32 n_groups, u32 n_chunks, u32 chunk, int rel_bits, int32_t* __restrict__ chunk_rel,
-                                  int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_flags) {
+                                  u32 n_groups, u32 n_chunks, u32 chunk, u32 layout, const u64* __restrict__ ukeys, KeyLayout kl,
+                                  u32* __restrict__ split, int32_t* __restrict__ chunk_rel, int32_t* __restrict__ chunk_cnt,
+                                  int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_flags) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     // the group whose chunk range holds c: last g with chunk_base[g] <= c
@@ -399,13 +429,40 @@ __global__ void chunk_meta_kernel(const u32* __restrict__ chunk_base, const u32*
     }
     const u32 g = lo;
     const u32 cnt = gstart[g + 1] - gstart[g];
-    const u32 nt = (cnt + 15u) / 16u, per = chunk / 16u;
     const u32 idx = c - chunk_base[g];
-    const u32 left = nt - idx * per;
-    chunk_cnt[c] = (int32_t)((left < per ? left : per) * 16u);
-    chunk_rel[c] = (int32_t)(gkey[g] & ((1u << rel_bits) - 1u));
-    chunk_tile[c] = (int32_t)(gkey[g] >> rel_bits);
-    chunk_flags[c] = 0;
+    int32_t flags = 0;
+    if (layout == 0) {
+        const u32 nt = (cnt + 15u) / 16u, per = chunk / 16u;
+        const u32 left = nt - idx * per;
+        chunk_cnt[c] = (int32_t)((left < per ? left : per) * 16u);
+    } else {
+        const u32 left = cnt - idx * 128u, n_c = left < 128u ? left : 128u;
+        if (n_c <= 64u) {
+            chunk_cnt[c] = (int32_t)(((n_c + 15u) / 16u) * 16u);
+            split[c] = n_c;
+        } else {
+            // cut at the run boundary closest to ceil(n_c / 2) inside [n_c - 64, 64]: mid, mid - 1, mid + 1, mid - 2, ...
+            const u64* rows = ukeys + gstart[g] + (size_t)idx * 128u;
+            const u64 dmask = (1ull << kl.dstl_bits) - 1ull;
+            auto dst_of = [&](u32 j) { return (rows[j] >> kl.src_bits) & dmask; };
+            const int mid = (int)((n_c + 1u) / 2u), lo_s = (int)n_c - 64 > 1 ? (int)n_c - 64 : 1, hi_s = (int)n_c - 1 < 64 ? (int)n_c - 1 : 64;
+            int sp = -1;
+            for (int k = 0; k < 64 && sp < 0; ++k) {
+                const int a = mid - k, b = mid + k;
+                if (a >= lo_s && a <= hi_s && dst_of((u32)a - 1u) != dst_of((u32)a)) sp = a;
+                else if (k > 0 && b >= lo_s && b <= hi_s && dst_of((u32)b - 1u) != dst_of((u32)b)) sp = b;
+            }
+            if (sp < 0) {      // one destination's run covers the whole window: the halves share it
+                sp = mid < lo_s ? lo_s : (mid > hi_s ? hi_s : mid);
+                flags = 256;
+            }
+            split[c] = (u32)sp;
+            chunk_cnt[c] = (int32_t)((4u + (n_c - (u32)sp + 15u) / 16u) * 16u);
+        }
+    }
+    chunk_rel[c] = (int32_t)(gkey[g] & ((1u << kl.rel_bits) - 1u));
+    chunk_tile[c] = (int32_t)(gkey[g] >> kl.rel_bits);
+    chunk_flags[c] = flags;
 }
 
 // per 16-slot MFMA row tile: run metadata of the forward kernel's run-sum (plan.run_metadata), the dW kernels' row ids
@@ -571,7 +628,7 @@ static int check_graph(const rgcn_graph_t* g) {
 // internal state handed from _begin to _finish (lives in rgcn_plan_sizes_t::opaque)
 struct BuildState {
     u32 magic;
-    u32 n_nodes, n_own, node_begin, num_rel, tile, chunk;
+    u32 n_nodes, n_own, node_begin, num_rel, tile, chunk, layout;
     u32 n_unique, n_groups, n_chunks, n_units, n_edges_owned;
     u32 ubuf;               // index of the SortBufs pair holding the merged (key, weight) arrays
     u64 nmax, gmax;
@@ -631,12 +688,13 @@ extern "C" int rgcn_edge_weights(const rgcn_graph_t* g, int aggr_sum, float* w, 
 }
 
 extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int transposed, int32_t node_begin, int32_t node_end,
-                                     int32_t tile, int32_t chunk, void* workspace, size_t workspace_bytes,
+                                     int32_t tile, int32_t chunk, int32_t layout, void* workspace, size_t workspace_bytes,
                                      rgcn_plan_sizes_t* sizes, void* stream) {
     int st = check_graph(g);
     if (st != RGCN_OK) return st;
     if (!sizes || !workspace || (g->num_edges > 0 && !w)) return RGCN_ERR_NULL;
     if (tile <= 0 || (tile % 16) != 0 || tile > 32768 || (chunk != 64 && chunk != 128)) return RGCN_ERR_PLAN;
+    if (layout != 0 && !(layout == 1 && chunk == 128)) return RGCN_ERR_PLAN;
     if (node_begin < 0 || node_end <= node_begin || node_end > g->num_nodes || (node_begin % tile) != 0) return RGCN_ERR_PLAN;
     hipStream_t s = (hipStream_t)stream;
     const u32 n_own = (u32)(node_end - node_begin), R = (u32)g->num_relations;
@@ -686,7 +744,7 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     if ((u64)n_groups + 1 > gmax) return RGCN_ERR_PLAN;
     hipLaunchKernelGGL(group_start_kernel, dim3(grid_for(n_unique)), dim3(256), 0, s, ws.sb.k[ub], n_unique, kl.gshift(), ws.scan_b,
                        ws.gstart, ws.gkey, n_groups);
-    hipLaunchKernelGGL(group_sizes_kernel, dim3(grid_for(n_groups)), dim3(256), 0, s, ws.gstart, n_groups, (u32)chunk, ws.gch, ws.gun);
+    hipLaunchKernelGGL(group_sizes_kernel, dim3(grid_for(n_groups)), dim3(256), 0, s, ws.gstart, n_groups, (u32)chunk, (u32)layout, ws.gch, ws.gun);
     u32 n_chunks = 0, n_units = 0;
     exclusive_scan(ws.gun, ws.gun, n_groups, ws.sb.sums, s);
     if ((st = read_u32(ws.sb.sums + scan_blocks(n_groups), &n_units, s)) != 0) return st;
@@ -703,7 +761,7 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     memset(&bs, 0, sizeof(bs));
     bs.magic = kMagic;
     bs.n_nodes = (u32)g->num_nodes; bs.n_own = n_own; bs.node_begin = (u32)node_begin; bs.num_rel = R;
-    bs.tile = (u32)tile; bs.chunk = (u32)chunk;
+    bs.tile = (u32)tile; bs.chunk = (u32)chunk; bs.layout = (u32)layout;
     bs.n_unique = n_unique; bs.n_groups = n_groups; bs.n_chunks = n_chunks; bs.n_units = n_units; bs.n_edges_owned = owned;
     bs.ubuf = (u32)ub; bs.nmax = nmax; bs.gmax = gmax; bs.kl = kl;
     memcpy(sizes->opaque, &bs, sizeof(bs));
@@ -733,10 +791,11 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     int32_t* chunk_flags = (int32_t*)plan->chunk_flags;
     u32* dstl = (u32*)slot_row;   // scratch inside the output array until row_tile_kernel (see fill_slots_kernel)
     hipLaunchKernelGGL(fill_slots_kernel, dim3(grid_for(n_slots)), dim3(256), 0, s, n_slots, bs.n_nodes, bs.tile, slot_src, slot_w, dstl);
-    hipLaunchKernelGGL(place_kernel, dim3(grid_for(bs.n_unique)), dim3(256), 0, s, ws.sb.k[bs.ubuf], ws.sb.v[bs.ubuf], bs.n_unique,
-                       ws.scan_b, ws.gstart, ws.gch, bs.chunk, bs.kl, slot_src, slot_w, dstl);
+    u32* split = ws.scan_a;       // cut position of every chunk (layout 1); n_chunks <= nmax
     hipLaunchKernelGGL(chunk_meta_kernel, dim3(grid_for(bs.n_chunks)), dim3(256), 0, s, ws.gch, ws.gstart, ws.gkey, bs.n_groups,
-                       bs.n_chunks, bs.chunk, bs.kl.rel_bits, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
+                       bs.n_chunks, bs.chunk, bs.layout, ws.sb.k[bs.ubuf], bs.kl, split, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
+    hipLaunchKernelGGL(place_kernel, dim3(grid_for(bs.n_unique)), dim3(256), 0, s, ws.sb.k[bs.ubuf], ws.sb.v[bs.ubuf], bs.n_unique,
+                       ws.scan_b, ws.gstart, ws.gch, bs.chunk, bs.layout, split, bs.kl, slot_src, slot_w, dstl);
     hipLaunchKernelGGL(row_tile_kernel, dim3(grid_for(n_rt)), dim3(256), 0, s, dstl, n_rt, bs.chunk, bs.tile, bs.n_own, chunk_tile,
                        slot_acc, slot_row, chunk_flags);
     const u32 n_tiles = (bs.n_own + bs.tile - 1) / bs.tile;
@@ -760,5 +819,6 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     plan->n_chunks = (int32_t)bs.n_chunks;
     plan->chunk = (int32_t)bs.chunk;
     plan->n_units = (int32_t)bs.n_units;
+    plan->layout = (int32_t)bs.layout;
     return (int)hipGetLastError();
 }

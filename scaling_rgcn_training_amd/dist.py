@@ -53,7 +53,7 @@ class RankPlans:
 
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
-               aggr: str, dctx: DistContext, chunk: int = 64) -> RankPlans:
+               aggr: str, dctx: DistContext, chunk: int = 64, split: bool = False) -> RankPlans:
     """Plans of this rank's blocks.  The mean normaliser (a sort of all E keys) is computed ONCE and every piece is
     laid out from the same edge list: on the GPU by the library's plan builder with the piece's node range (it keeps
     the edges that scatter into the range), on the CPU (tests) by the torch form from this rank's share."""
@@ -61,7 +61,7 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
     if edge_type.device.type == "cuda":
         from .plan import build_graph_plans_device
         return RankPlans(build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
-                                                  ranges=[(r, r) for r in ranges]))
+                                                  ranges=[(r, r) for r in ranges], split=split))
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = edge_type.to(torch.int64)
     w = edge_weights(src, dst, rel, num_relations, aggr)
@@ -77,17 +77,17 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
     out = []
     for s, (b, e) in enumerate(ranges):
         fm, bm = fpiece == s, bpiece == s
-        fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk)
-        bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk)
+        fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk, split)
+        bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk, split)
         out.append(GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(fm.sum())))
     return RankPlans(out)
 
 
 def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext,
-                      chunk: int = 64) -> RankPlans:
+                      chunk: int = 64, split: bool = False) -> RankPlans:
     return cached_graph_plans(
-        edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
-        builder=lambda: rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx, chunk),
+        edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split,
+        builder=lambda: rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx, chunk, split),
         extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, dctx.piece_rows))
 
 

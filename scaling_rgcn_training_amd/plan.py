@@ -66,6 +66,7 @@ class TilePlan:
                           #   None for plans built on the device
     slot_row: Tensor      # int32 [n_chunks * chunk]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
     slot_acc: Tensor      # int32 [n_chunks * chunk]  run-end position << 24 | accumulator row
+    layout: int = 0       # 0: rows of a group dealt over all its row tiles; 1: split placement (split_placement)
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -103,14 +104,17 @@ def edge_weights(src: Tensor, dst: Tensor, rel: Tensor, num_relations: int, aggr
 
 def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes: int,
                num_relations: int, tile: int, node_begin: int = 0,
-               node_end: Optional[int] = None, chunk: int = CHUNK) -> TilePlan:
+               node_end: Optional[int] = None, chunk: int = CHUNK, split: bool = False) -> TilePlan:
     """Lay out the edges scattering into ``[node_begin, node_end)``.
 
     gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src).
     chunk: edge slots per chunk (one of CHUNKS).
+    split: the SPLIT placement (layout 1, 128-slot chunks only), see ``split_placement``.
     """
     if chunk not in CHUNKS:
         raise ValueError(f"chunk must be one of {CHUNKS}")
+    if split and chunk != 128:
+        raise ValueError("the split placement needs 128-slot chunks")
     CHUNK = chunk  # noqa: N806  (shadows the module default inside this function)
     if node_end is None:
         node_end = n_nodes
@@ -170,8 +174,16 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     # destinations and the forward kernel can skip its run-sum product for them (chunk_flags).
     g16 = ROWS_PER_MFMA_TILE
     gnt = (gcnt + (g16 - 1)) // g16
-    nt_e = gnt[grp_of_edge]
-    slot = chunk_base[grp_of_edge] * CHUNK + (rank % nt_e) * g16 + rank // nt_e
+    grp_of_chunk = torch.repeat_interleave(torch.arange(n_groups, device=dev), gch)
+    idx_in_grp = torch.arange(n_chunks, device=dev) - chunk_base[grp_of_chunk]
+    straddle = None
+    if not split:
+        nt_e = gnt[grp_of_edge]
+        slot = chunk_base[grp_of_edge] * CHUNK + (rank % nt_e) * g16 + rank // nt_e
+        # slots of the chunk's used row tiles (a multiple of 16; padding sits at the end of every tile)
+        chunk_cnt = (torch.clamp(gnt[grp_of_chunk] - idx_in_grp * (CHUNK // g16), max=CHUNK // g16) * g16).to(torch.int32)
+    else:
+        slot, chunk_cnt, straddle = split_placement(dstl, gcnt, grp_of_edge, rank, chunk_base, grp_of_chunk, idx_in_grp)
     n_slots = n_chunks * CHUNK
     slot_src = torch.full((n_slots,), n_nodes, dtype=torch.int32, device=dev)  # padding: one past the last row
     slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
@@ -182,14 +194,12 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     slot_acc, tile_dup = run_metadata(slot_dstl, tile)
     chunk_flags = (tile_dup.view(-1, CHUNK // g16).to(torch.int32)
                    * (2 ** torch.arange(CHUNK // g16, device=dev, dtype=torch.int32))).sum(1).to(torch.int32)
-    grp_of_chunk = torch.repeat_interleave(torch.arange(n_groups, device=dev), gch)
+    if straddle is not None:
+        chunk_flags = chunk_flags | (straddle.to(torch.int32) << 8)
     # the dW kernel gathers the upstream-gradient row of every slot: its index in the owned range
     tile_of_slot = torch.repeat_interleave((gvals[grp_of_chunk] // r1).to(torch.int32), CHUNK)
     slot_row = torch.where(slot_dstl < tile, tile_of_slot * tile + slot_dstl,
                            torch.full_like(slot_dstl, n_own))
-    idx_in_grp = torch.arange(n_chunks, device=dev) - chunk_base[grp_of_chunk]
-    # slots of the chunk's used row tiles (a multiple of 16; padding sits at the end of every tile)
-    chunk_cnt = (torch.clamp(gnt[grp_of_chunk] - idx_in_grp * (CHUNK // g16), max=CHUNK // g16) * g16).to(torch.int32)
     chunk_rel = (gvals[grp_of_chunk] % r1).to(torch.int32)
     chunk_tile = (gvals[grp_of_chunk] // r1).to(torch.int32)
     n_tiles = (n_own + tile - 1) // tile
@@ -208,7 +218,55 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     num_relations=num_relations, tile=tile, chunk=CHUNK, n_tiles=n_tiles, n_chunks=n_chunks,
                     n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
-                    slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags)
+                    slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags,
+                    layout=1 if split else 0)
+
+
+def split_placement(dstl: Tensor, gcnt: Tensor, grp_of_edge: Tensor, rank: Tensor, chunk_base: Tensor,
+                    grp_of_chunk: Tensor, idx_in_grp: Tensor):
+    """Layout 1 (128-slot chunks): chunk c of a group takes the group's sorted rows [128 c, 128 c + 128) -- n_c of them.
+    With n_c > 64 the rows are cut at a RUN BOUNDARY s (the destination changes between rows s - 1 and s) into two parts
+    of at most 64 rows: part 0 is dealt over row tiles 0..3 of the chunk (row j -> tile j mod 4, place j div 4), part 1 over
+    tiles 4 .. 4 + nt1 - 1, nt1 = ceil((n_c - s) / 16).  So the two 64-slot halves of a chunk hold DISJOINT destination
+    sets and can be accumulated by different waves at the same time (the bf16x3 forward / dX kernel: a wave pair per
+    half).  s is the boundary closest to ceil(n_c / 2) inside [n_c - 64, 64], the lower one on a tie; a chunk without
+    one (a single destination's run covers the window) is cut at the middle and flagged (chunk_flags bit 8: the halves
+    share a destination).  n_c <= 64: all rows in part 0, dealt over ceil(n_c / 16) tiles as in layout 0.
+    The used row tiles of a chunk stay contiguous from tile 0, so chunk_cnt keeps its meaning for every kernel.
+    Returns (slot of every row, chunk_cnt, straddle flag per chunk)."""
+    C, g16 = 128, ROWS_PER_MFMA_TILE
+    dev = dstl.device
+    n_chunks = int(grp_of_chunk.shape[0])
+    n_c_chunk = torch.clamp(gcnt[grp_of_chunk] - idx_in_grp * C, max=C)
+    big_c = n_c_chunk > 64
+    mid_c = (n_c_chunk + 1) // 2
+    lo_c = torch.clamp(n_c_chunk - 64, min=1)
+    hi_c = torch.clamp(n_c_chunk - 1, max=64)
+    cidx = rank // C
+    jc = rank - cidx * C
+    chunk_of_row = chunk_base[grp_of_edge] + cidx
+    prev_dstl = torch.cat([dstl[:1], dstl[:-1]])
+    boundary = (jc >= 1) & (dstl != prev_dstl)             # jc >= 1: row jc - 1 belongs to the same chunk range
+    cand = boundary & big_c[chunk_of_row] & (jc >= lo_c[chunk_of_row]) & (jc <= hi_c[chunk_of_row])
+    dist = jc - mid_c[chunk_of_row]
+    score = 2 * dist.abs() + (dist > 0).to(torch.int64)    # mid, mid - 1, mid + 1, mid - 2, ...
+    big_score = 1 << 20
+    best = torch.full((n_chunks,), big_score, dtype=torch.int64, device=dev)
+    best = best.scatter_reduce(0, chunk_of_row[cand], score[cand], reduce="amin", include_self=True)
+    has = best < big_score
+    k = best // 2
+    s_found = torch.where(best % 2 == 1, mid_c + k, mid_c - k)
+    s_c = torch.where(has, s_found, torch.minimum(torch.maximum(mid_c, lo_c), hi_c))
+    straddle = big_c & ~has
+    nt1_c = (n_c_chunk - s_c + (g16 - 1)) // g16
+    nts_c = (n_c_chunk + (g16 - 1)) // g16
+    chunk_cnt = torch.where(big_c, (4 + nt1_c) * g16, nts_c * g16).to(torch.int32)
+    s_r, big_r = s_c[chunk_of_row], big_c[chunk_of_row]
+    nts_r, nt1_r = nts_c[chunk_of_row], torch.clamp(nt1_c[chunk_of_row], min=1)
+    j1 = torch.clamp(jc - s_r, min=0)
+    in_chunk = torch.where(~big_r, (jc % nts_r) * g16 + jc // nts_r,
+                           torch.where(jc < s_r, (jc % 4) * g16 + jc // 4, 64 + (j1 % nt1_r) * g16 + j1 // nt1_r))
+    return chunk_of_row * C + in_chunk, chunk_cnt, straddle
 
 
 import os as _os
@@ -349,30 +407,32 @@ class GraphPlans:
 def build_graph_plans_torch(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
                             tile: int, aggr: str = "mean",
                             fwd_range: Optional[Tuple[int, int]] = None,
-                            bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK) -> GraphPlans:
+                            bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
+                            split: bool = False) -> GraphPlans:
     """The plans as torch tensor ops (any device): the TEST ORACLE of the device-side builder and what the CPU-only
     tests walk with tests/plan_emulator.py."""
     src, dst = edge_index[0], edge_index[1]
     w = edge_weights(src, dst, edge_type, num_relations, aggr)
     fb, fe = fwd_range if fwd_range is not None else (0, n_nodes)
     bb, be = bwd_range if bwd_range is not None else (0, n_nodes)
-    fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe, chunk)
-    bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be, chunk)
+    fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe, chunk, split)
+    bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be, chunk, split)
     return GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(edge_type.shape[0]))
 
 
 def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, tile: int, chunk: int,
-                 node_begin: int, node_end: int, ws) -> TilePlan:
+                 node_begin: int, node_end: int, ws, split: bool = False) -> TilePlan:
     from . import _lib
     if node_end <= node_begin:           # a block wholly past the last node (dist.py): nothing to lay out
         z = lambda dt=torch.int32: torch.zeros(0, dtype=dt, device=ws.device)
         return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_begin, num_relations=num_relations, tile=tile,
                         chunk=chunk, n_tiles=0, n_chunks=0, n_edges=0, tile_ptr=torch.zeros(1, dtype=torch.int32, device=ws.device),
                         chunk_rel=z(), chunk_cnt=z(), chunk_tile=z(), chunk_flags=z(), rel_order=z(), slot_src=z(),
-                        slot_w=z(torch.float32), slot_dstl=None, slot_row=z(), slot_acc=z())
-    ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, tile, chunk, ws)
+                        slot_w=z(torch.float32), slot_dstl=None, slot_row=z(), slot_acc=z(), layout=int(split))
+    ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, tile, chunk, ws, split)
     plan = TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, tile=tile,
-                    chunk=chunk, n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None, **a)
+                    chunk=chunk, n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None,
+                    layout=int(split), **a)
     plan._cstruct = ps
     return plan
 
@@ -380,7 +440,7 @@ def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, t
 def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
                              aggr: str = "mean", fwd_range: Optional[Tuple[int, int]] = None,
                              bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
-                             ranges=None):
+                             ranges=None, split: bool = False):
     """The plans built by the HIP library itself (csrc/rgcn_plan.hip through rgcn_edge_weights / rgcn_plan_build_*):
     what every GPU forward uses.  ``ranges``: a list of (begin, end) owned ranges -> a list of GraphPlans that share one
     edge-weight pass and one workspace (dist.py: one pair of plans per owned block)."""
@@ -400,8 +460,8 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
         raise
     out = []
     for (fb, fe), (bb, be) in rs:
-        fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws)
-        bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws)
+        fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws, split)
+        bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
         out.append(GraphPlans(fwd=fwd, bwd=bwd, num_edges=fwd.n_edges if ranges is not None else e))
     del keep
     return out if ranges is not None else out[0]
@@ -410,11 +470,13 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
 def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
                       tile: int, aggr: str = "mean",
                       fwd_range: Optional[Tuple[int, int]] = None,
-                      bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK) -> GraphPlans:
+                      bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
+                      split: bool = False) -> GraphPlans:
     """Device tensors: the HIP plan builder behind the C ABI.  CPU tensors (tests without a GPU): the torch form."""
     if edge_type.device.type == "cuda" and _WALK_MODE == "sorted":
-        return build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk)
-    return build_graph_plans_torch(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk)
+        return build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk,
+                                        split=split)
+    return build_graph_plans_torch(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk, split)
 
 
 def balanced_ranges(counts_per_tile: Tensor, world: int, tile: int, n_nodes: int):
@@ -448,17 +510,17 @@ def _plans_nbytes(plans) -> int:
 
 
 def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
-                       tile: int, aggr: str, builder=None, extra_key=(), chunk: int = CHUNK) -> GraphPlans:
+                       tile: int, aggr: str, builder=None, extra_key=(), chunk: int = CHUNK, split: bool = False) -> GraphPlans:
     """LRU over (edge tensors' identity, layout): at most ``_CACHE_MAX`` entries and ``RGCN_PLAN_CACHE_GB`` (48) GiB of
     plan arrays (4.3 GB per 100M edges), least recently used evicted first."""
     key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
-           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr) + tuple(extra_key)
+           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr, bool(split)) + tuple(extra_key)
     hit = _CACHE.pop(key, None)
     if hit is not None:
         _CACHE[key] = hit           # most recently used last
         return hit[0]
     if builder is None:
-        plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk)
+        plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split)
     else:
         plans = builder()
     nbytes = _plans_nbytes(plans)

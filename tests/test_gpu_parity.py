@@ -19,14 +19,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _abi_layer(dev, ei, et, n, num_rel, x, w_full, root, bias, dout_grad, tile=None, aggr="mean", chunk=None, flags=0):
+def _abi_layer(dev, ei, et, n, num_rel, x, w_full, root, bias, dout_grad, tile=None, aggr="mean", chunk=None, flags=0, split=False):
     """forward, dX, dW through the raw C-ABI wrappers (no autograd)."""
     from scaling_rgcn_training_amd import _lib, plan as P
     from scaling_rgcn_training_amd.conv import layout_for, _rows16, _round4
     din, dout = w_full.shape[1], w_full.shape[2]
     t0, c0 = layout_for(din, dout, n, int(et.shape[0]), num_rel)
     tile, chunk = tile or t0, chunk or c0
-    plans = P.build_graph_plans(ei.to(dev), et.to(dev), n, num_rel, tile, aggr, chunk=chunk)
+    plans = P.build_graph_plans(ei.to(dev), et.to(dev), n, num_rel, tile, aggr, chunk=chunk, split=split)
     xd = _rows16(x.to(dev), din)
     gd = _rows16(dout_grad.to(dev), dout)
     wd = w_full.to(dev).contiguous()
@@ -372,3 +372,30 @@ def test_fused_activation_standalone_relu_backward(dev):
         res.append([out.detach(), x.grad, conv.weight.grad.clone(), conv.root.grad.clone(), conv.bias.grad.clone()])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,e,r,tile,skew", [(3000, 330000, 3, 352, False), (2000, 200000, 4, 128, True), (5000, 90000, 7, 352, False),
+                                             (800, 120000, 2, 64, True)])
+def test_split_precision_kernel_matches_oracle(dev, n, e, r, tile, skew):
+    """The bf16 x 3 forward / dX kernel (64 x 64, layout-1 plans: groups of 100+ edges so that chunks fill both halves,
+    hubs so that some chunks' halves share a destination -- flag 256 -- and row tiles repeat destinations) against the float64
+    oracle under both bounds of oracle/tolerance.py, and against the exact-fp32 kernel on the same plan."""
+    from scaling_rgcn_training_amd import _lib
+    din = dout = 64
+    ei, et = O.synthetic_graph(n, e, r, seed=n + r, skew=skew)
+    ei[:, 100:160] = ei[:, 20:80]           # duplicate triples
+    et[100:160] = et[20:80]
+    w, root, bias = O.synthetic_params(r, din, dout, seed=9)
+    g = torch.Generator().manual_seed(17)
+    bias = torch.randn(dout, generator=g) * 0.1
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    res3 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, split=True)
+    _check_layer(res3, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [bf16x3 T{tile} n{n}]")
+    res1 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, split=True, flags=_lib.FLAG_EXACT_FP32)
+    _check_layer(res1, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [fp32 on layout 1 T{tile} n{n}]")
+    # the two kernels agree far inside the tolerance (different summation orders, same 24-bit operands)
+    for a, b in zip(res3[:2], res1[:2]):
+        assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, float(np.abs(b).max()))
+    assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel

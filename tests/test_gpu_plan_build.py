@@ -15,14 +15,17 @@ ARRAYS = ("tile_ptr", "chunk_rel", "chunk_cnt", "chunk_tile", "chunk_flags", "re
           "slot_acc")
 
 
-def _compare(ei, et, n, r, tile, chunk, aggr="mean", fr=None, br=None):
+def _compare(ei, et, n, r, tile, chunk, aggr="mean", fr=None, br=None, split=False):
     from scaling_rgcn_training_amd import plan as P
-    dev_plans = P.build_graph_plans_device(ei, et, n, r, tile, aggr, fr, br, chunk)
-    ref_plans = P.build_graph_plans_torch(ei, et, n, r, tile, aggr, fr, br, chunk)
+    if chunk == 128 and not split:          # every 128-slot case also in the split placement (plan layout 1)
+        _compare(ei, et, n, r, tile, chunk, aggr, fr, br, split=True)
+    dev_plans = P.build_graph_plans_device(ei, et, n, r, tile, aggr, fr, br, chunk, split=split)
+    ref_plans = P.build_graph_plans_torch(ei, et, n, r, tile, aggr, fr, br, chunk, split=split)
     torch.cuda.synchronize()
     for name in ("fwd", "bwd"):
         a, b = getattr(dev_plans, name), getattr(ref_plans, name)
-        for f in ("n_nodes", "node_begin", "node_end", "num_relations", "tile", "chunk", "n_tiles", "n_chunks", "n_edges", "n_units"):
+        for f in ("n_nodes", "node_begin", "node_end", "num_relations", "tile", "chunk", "n_tiles", "n_chunks", "n_edges", "n_units",
+                  "layout"):
             assert getattr(a, f) == getattr(b, f), (name, f, getattr(a, f), getattr(b, f))
         for f in ARRAYS:
             x, y = getattr(a, f), getattr(b, f)
@@ -92,7 +95,7 @@ def test_plan_build_10m_edges_bit_identical_and_timed():
     _compare(ei, et, n, r, tile, chunk)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    P.build_graph_plans_device(ei, et, n, r, tile, "mean", None, None, chunk)
+    P.build_graph_plans_device(ei, et, n, r, tile, "mean", None, None, chunk, split=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"device plan build, 10M edges: {dt * 1e3:.1f} ms")
