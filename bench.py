@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--width", type=int, default=HEADLINE[3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ladder", action="store_true")
+    ap.add_argument("--split-precision", action="store_true",
+                    help="forward / dX on the bf16x3 split-precision kernel and layout-1 plans (default: exact-fp32 MFMA kernel)")
     args = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -194,6 +196,7 @@ def main():
     log(f"rank {rank}/{world}: generating {n} nodes / {e} edges / {r} relations on {torch.cuda.get_device_name(dev)}")
     ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, d, d, dev)
     conv = RGCNConv(d, d, r).to(dev)
+    conv.split_precision = bool(args.split_precision)
     with torch.no_grad():
         conv.weight.copy_(weight)
         conv.root.copy_(root)
@@ -281,13 +284,15 @@ def main():
     psf = [(_lib.plan_struct(p), p) for p in fps]
     psb = [(_lib.plan_struct(p), p) for p in bps]
 
+    kf = conv.kernel_flags
+
     def run_fwd():
         for ps, p in psf:
-            _lib.fwd(ps, xd, d, pk, bs, out[:p.n_owned], d)
+            _lib.fwd(ps, xd, d, pk, bs, out[:p.n_owned], d, 0, kf)
 
     def run_dx():
         for ps, p in psb:
-            _lib.bwd_dx(ps, dg, d, pkt, dxb[:p.n_owned], d)
+            _lib.bwd_dx(ps, dg, d, pkt, dxb[:p.n_owned], d, None, kf)
 
     def run_dw():
         for ps, p in psf:

@@ -39,6 +39,7 @@ def _rows16(t: Tensor, width: int) -> Tensor:
 # experiment overrides of the (tile, chunk) layout: read ONCE at import, never on the forward path
 _ENV_TILE = int(os.environ["RGCN_TILE"]) if "RGCN_TILE" in os.environ else None
 _ENV_CHUNK = int(os.environ["RGCN_CHUNK"]) if "RGCN_CHUNK" in os.environ else None
+_SPLIT_PRECISION_DEFAULT = os.environ.get("RGCN_SPLIT_PRECISION", "0") == "1"
 
 _ACT_CODES = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID}
 
@@ -283,6 +284,10 @@ class RGCNConv(nn.Module):
         self.dist: Optional[DistContext] = None
         self._dist_plans = None
         self.kernel_flags = 0     # RGCN_FLAG_* passed to every launch of this layer (tests pin kernel paths with it)
+        # True: lay the plans out for, and run forward / dX on, the split-precision (bf16 x 3, fp32-equivalent) kernel
+        # where it exists (64 x 64, dense groups).  Off by default: measured no faster than the exact-fp32 kernel
+        # (10.9 vs 10.6 ms per launch at the headline config).
+        self.split_precision = _SPLIT_PRECISION_DEFAULT
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
             self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
@@ -336,7 +341,7 @@ class RGCNConv(nn.Module):
         n = x.shape[0]
         e = int(edge_type.shape[0])
         tile, chunk = layout_for(self.in_channels, self.out_channels, n, e, self.num_relations)
-        split = split_for(self.in_channels, self.out_channels, n, e, self.num_relations, tile, chunk)
+        split = self.split_precision and split_for(self.in_channels, self.out_channels, n, e, self.num_relations, tile, chunk)
         if self.dist is None:
             return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split)
         from .dist import cached_rank_plans

@@ -491,7 +491,32 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         int cnt_pre = ldc(a.chunk_cnt, c0);
         int flags_pre = ldc(a.chunk_flags, c0);
-        int rel_pre = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
+        // Relation ids one and two chunks ahead.  The NEXT relation's weight fragments are prefetched into `bnext` at the
+        // END of an iteration, just before the barrier: by then the producers have issued (and waited for) all their
+        // LDS-DMAs, so the CU's vector-memory queue is empty and these few loads issue at once.  Issued at the TOP of
+        // an iteration -- right behind the barrier, when the producers flood the queue with the next chunk's 32 gathers --
+        // every global_load of a consumer wave took hundreds of cycles to ISSUE (~1,000 cycles per chunk, the "fixed cost
+        // that does not scale with the chunk" of the stamp profile; tools/debug/stamps.py).
+        constexpr bool kAsmPrefetch = SL * KT <= 4;
+        int rel_n1 = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
+        int rel_n2 = nch > 2 ? ldc(a.chunk_rel, c0 + 2) : rel_n1;
+        auto prefetch_rel = [&](int rel) {
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                const f32x4* bp = wp4 + ((size_t)(rel * NT + cw + CW * s) * KT) * 64 + lane;
+                if constexpr (kAsmPrefetch) {
+                    prefetch_b<KT>(bnext[s], bp);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) bnext[s][j] = bp[j * 64];
+                }
+            }
+        };
+        bool pending = false;       // bnext is receiving the fragments of chunk it + 1
+        if (kAsmPrefetch && active && rel_n1 != rel_cur && !(RGCN_DBG(a) & 4)) {
+            prefetch_rel(rel_n1);
+            pending = true;
+        }
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bwait = 0, st_bar = 0;
@@ -504,32 +529,22 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             // chunk metadata arrives one iteration ahead (scalar loads issued a whole chunk earlier)
             const int cnt = cnt_pre;
             const int flags_chunk = flags_pre;
-            const int rel_next = rel_pre;
+            const int rel_next = rel_n1;
+            const int rel_next2 = rel_n2;
             if (it + 1 < nch) {
                 cnt_pre = ldc(a.chunk_cnt, chunk + 1);
                 flags_pre = ldc(a.chunk_flags, chunk + 1);
             }
-            if (it + 2 < nch) rel_pre = ldc(a.chunk_rel, chunk + 2);
+            rel_n1 = rel_n2;
+            if (it + 3 < nch) rel_n2 = ldc(a.chunk_rel, chunk + 3);
 #ifdef RGCN_STAMPS
             asm volatile("" ::"s"(cnt), "s"(rel_next));
 #endif
             STAMP(t1);
-            const bool swap_b = active && rel_next != rel_cur && !(RGCN_DBG(a) & 4);
-            // the asm prefetch must never be spilled before its wait (hipcc believes the value is there):
-            // only used where the fragment sets fit the register file comfortably
-            constexpr bool kAsmPrefetch = SL * KT <= 4;
-            if (swap_b) {
-#pragma unroll
-                for (int s = 0; s < SL; ++s) {
-                    const f32x4* bp = wp4 + ((size_t)(rel_next * NT + cw + CW * s) * KT) * 64 + lane;
-                    if constexpr (kAsmPrefetch) {
-                        prefetch_b<KT>(bnext[s], bp);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < KT; ++j) bnext[s][j] = bp[j * 64];
-                    }
-                }
-            }
+            // (the asm prefetch must never be spilled before its wait -- hipcc believes the value is there --: only used
+            // where the fragment sets fit the register file comfortably; the plain-load form keeps the early prefetch)
+            const bool swap_b = kAsmPrefetch ? pending : (active && rel_next != rel_cur && !(RGCN_DBG(a) & 4));
+            if (!kAsmPrefetch && swap_b) prefetch_rel(rel_next);
             const int nrt_all = (!active || (RGCN_DBG(a) & 1)) ? 0 : (cnt + 15) >> 4;
             const int flags_all = flags_chunk & 0xFF;     // bit 8 (layout 1: the chunk's halves share a destination) is not ours
             // A chunk without repeated destinations runs as ONE straight-line block over all its row tiles (up to
@@ -806,6 +821,10 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
 #endif
             }
             rel_cur = rel_next;
+            if constexpr (kAsmPrefetch) {      // fragments of chunk it + 2, issued while the memory queue is idle
+                pending = active && it + 2 < nch && rel_next2 != rel_next && !(RGCN_DBG(a) & 4);
+                if (pending) prefetch_rel(rel_next2);
+            }
             STAMP(t3);
             wg_barrier();
             STAMP(t4);
@@ -952,31 +971,46 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile3_kern
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire these loads in the compiler's scoreboard (see rgcn_tile_kernel)
         int cnt_pre = ldc(a.chunk_cnt, c0);
         int flags_pre = ldc(a.chunk_flags, c0);
-        int rel_pre = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
+        // next relation's fragments: prefetched at the END of an iteration, while the CU's memory queue is idle (rgcn_tile_kernel)
+        int rel_n1 = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
+        int rel_n2 = nch > 2 ? ldc(a.chunk_rel, c0 + 2) : rel_n1;
+        auto prefetch_rel = [&](int rel) {
+            const f32x4* bp = (const f32x4*)(wp4 + (size_t)(rel * 2 + ch) * (3 * 2 * 2 * 64) + lane);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4* bq = bp + q * 4 * 64;
+                prefetch16<0>(wnext[q][0][0], bq);
+                prefetch16<1024>(wnext[q][0][1], bq);
+                prefetch16<2048>(wnext[q][1][0], bq);
+                prefetch16<3072>(wnext[q][1][1], bq);
+            }
+        };
+        bool pending = rel_n1 != rel_cur;
+        if (pending) prefetch_rel(rel_n1);
         wg_barrier();
+#ifdef RGCN_STAMPS
+        unsigned long long st_scal = 0, st_comp = 0, st_bwait = 0, st_bar = 0;
+        unsigned long long st_pro = 0, st_top = 0, st_mid = 0, st_acc = 0;
+#endif
         for (int it = 0; it < nch; ++it) {
+            STAMP(t0);
             const int chunk = c0 + it;
             const int buf = it % NBUF;
             const int cnt = cnt_pre;
             const int flags = flags_pre;
-            const int rel_next = rel_pre;
+            const int rel_next = rel_n1;
+            const int rel_next2 = rel_n2;
             if (it + 1 < nch) {
                 cnt_pre = ldc(a.chunk_cnt, chunk + 1);
                 flags_pre = ldc(a.chunk_flags, chunk + 1);
             }
-            if (it + 2 < nch) rel_pre = ldc(a.chunk_rel, chunk + 2);
-            const bool swap_b = rel_next != rel_cur;
-            if (swap_b) {      // the next relation's fragments, on their way under this chunk's MFMAs
-                const f32x4* bp = (const f32x4*)(wp4 + (size_t)(rel_next * 2 + ch) * (3 * 2 * 2 * 64) + lane);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const f32x4* bq = bp + q * 4 * 64;
-                    prefetch16<0>(wnext[q][0][0], bq);
-                    prefetch16<1024>(wnext[q][0][1], bq);
-                    prefetch16<2048>(wnext[q][1][0], bq);
-                    prefetch16<3072>(wnext[q][1][1], bq);
-                }
-            }
+            rel_n1 = rel_n2;
+            if (it + 3 < nch) rel_n2 = ldc(a.chunk_rel, chunk + 3);
+#ifdef RGCN_STAMPS
+            asm volatile("" ::"s"(cnt), "s"(rel_next));
+#endif
+            STAMP(t1);
+            const bool swap_b = pending;
             // this wave's row tiles of the chunk: the used tiles are contiguous from tile 0; layout 1 puts a chunk of more
             // than 64 rows into tiles 0..3 (half 0) and 4.. (half 1) with disjoint destinations
             const int nt = cnt >> 4;
@@ -1099,7 +1133,131 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile3_kern
                     }
                 }
             };
-            if (n_my > 0) {
+            // ---- fast path: none of this wave's row tiles repeats a destination (nearly all chunks) -------------------
+            // Straight-line over the wave's NT tiles, software-pipelined by hand: the 88-instruction split of tile t + 1
+            // is issued BETWEEN the 24 MFMAs of tile t (a bf16 MFMA holds the SIMD's issue port for half of its 16
+            // cycles only), the operand reads of tile t + 2 and the accumulator read of tile t go out before them.
+            auto split3 = [&](const Ops& o, bf16x8 (&pl)[3][2]) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float x0 = o.x[s2][d >> 1][2 * (d & 1)], x1 = o.x[s2][d >> 1][2 * (d & 1) + 1];
+                        const unsigned h = cvt_pk_bf16(x0, x1);
+                        x0 -= __uint_as_float(h << 16);
+                        x1 -= __uint_as_float(h & 0xFFFF0000u);
+                        const unsigned m = cvt_pk_bf16(x0, x1);
+                        x0 -= __uint_as_float(m << 16);
+                        x1 -= __uint_as_float(m & 0xFFFF0000u);
+                        hh[d] = h;
+                        mm[d] = m;
+                        ll[d] = cvt_pk_bf16(x0, x1);
+                    }
+                    pl[0][s2] = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+                    pl[1][s2] = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
+                    pl[2][s2] = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+                }
+            };
+            auto consume3 = [&](auto nt_c) {
+                constexpr int NT = decltype(nt_c)::value;
+                constexpr int px[6] = {0, 0, 1, 0, 2, 1}, pw[6] = {0, 1, 0, 2, 0, 1};     // x plane, W plane: hh hm mh hl lh mm
+                Ops o[2];
+                bf16x8 pl[2][3][2];
+                STAMP(q0);
+                load_ops(o[0], first);
+                if constexpr (NT > 1) load_ops(o[1], first + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                split3(o[0], pl[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef RGCN_STAMPS
+                asm volatile("" ::"v"(pl[0][0][0]), "v"(pl[0][2][1]));
+#endif
+                STAMP(q1);
+                STAMP_ADD(st_pro, q0, q1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int cur = t & 1, nxt = cur ^ 1;
+                    STAMP(r0);
+                    // accumulator contents (after tile t - 1's store in program order: consecutive tiles may share a row)
+                    float* dst = acc_ptr(o[cur].d1, col4_bytes);
+                    const float w1 = o[cur].w1;
+                    f32x4 old[2], y[2];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        old[ct] = *(const f32x4*)(dst + 16 * ct);
+                        y[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (t + 2 < NT) load_ops(o[cur], first + t + 2);       // its fp32 contents were split an iteration ago
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef RGCN_STAMPS
+                    unsigned long long r1;      // (no lgkmcnt drain here: the reads just issued must stay in flight)
+                    asm volatile("s_memtime %0" : "=s"(r1)::"memory");
+#endif
+                    if (t + 1 < NT) {
+                        if (RGCN_ABL & 2) {        // diagnostic: no split (opaque copies keep the operand reads alive)
+#pragma unroll
+                            for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+                                for (int b2 = 0; b2 < 2; ++b2) {
+                                    f32x4 v = o[nxt].x[b2][a2 & 1];
+                                    asm volatile("" : "+v"(v));
+                                    pl[nxt][a2][b2] = __builtin_bit_cast(bf16x8, v);
+                                }
+                        } else {
+                            split3(o[nxt], pl[nxt]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) {
+                                if (RGCN_ABL & 1) {    // diagnostic: no MFMA
+                                    y[ct] += __builtin_bit_cast(f32x4, pl[cur][px[q]][s2]);
+                                    continue;
+                                }
+                                y[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[pw[q]][ct][s2]),
+                                                                                pl[cur][px[q]][s2], y[ct], 0, 0, 0);
+                            }
+                    if (t + 1 < NT && RGCN_ABL == 0) {
+#pragma unroll
+                        for (int i = 0; i < 22; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU of the next tile's split
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef RGCN_STAMPS
+                    asm volatile("" ::"v"(y[0]), "v"(y[1]));
+                    unsigned long long r2;
+                    asm volatile("s_nop 7\n\ts_memtime %0" : "=s"(r2)::"memory");
+#endif
+                    if (RGCN_ABL & 4) {            // diagnostic: no accumulator store
+                        asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(old[0]), "v"(old[1]));
+                    } else {
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) *(f32x4*)(dst + 16 * ct) = y[ct] * w1 + old[ct];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    STAMP(r3);
+#ifdef RGCN_STAMPS
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    st_top += r1 - r0; st_mid += r2 - r1; st_acc += r3 - r2;
+#endif
+                }
+            };
+            const int myflags = straddle ? (flags & 0xFF) : ((flags >> first) & 15);
+            using std::integral_constant;
+            if (n_my > 0 && myflags == 0 && n_my <= 4) {
+                switch (n_my) {
+                    case 1: consume3(integral_constant<int, 1>{}); break;
+                    case 2: consume3(integral_constant<int, 2>{}); break;
+                    case 3: consume3(integral_constant<int, 3>{}); break;
+                    default: consume3(integral_constant<int, 4>{}); break;
+                }
+            } else if (n_my > 0) {
                 Ops o0, o1;
                 load_ops(o0, first);
                 for (int t = 0; t < n_my; t += 2) {
@@ -1111,6 +1269,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile3_kern
                     }
                 }
             }
+            STAMP(t2);
             if (swap_b) {
                 wait_vmcnt<0>();      // the asm prefetch (this wave's only vector-memory traffic)
 #pragma unroll
@@ -1121,8 +1280,26 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile3_kern
                         for (int s2 = 0; s2 < 2; ++s2) wcur[q][ct][s2] = wnext[q][ct][s2];
             }
             rel_cur = rel_next;
+            pending = it + 2 < nch && rel_next2 != rel_next;
+            if (pending) prefetch_rel(rel_next2);
+#ifdef RGCN_STAMPS
+            asm volatile("" ::"v"(wcur[0][0][0]), "v"(wcur[2][1][1]));
+#endif
+            STAMP(t3);
             wg_barrier();
+            STAMP(t4);
+            STAMP_ADD(st_scal, t0, t1);
+            STAMP_ADD(st_comp, t1, t2);
+            STAMP_ADD(st_bwait, t2, t3);
+            STAMP_ADD(st_bar, t3, t4);
         }
+#ifdef RGCN_STAMPS
+        if (g_stamps && (cwv == 0 || cwv == 2) && lane == 0) {
+            unsigned long long* o = g_stamps + (size_t)blockIdx.x * 32 + (cwv == 2 ? 8 : 0);
+            o[0] = st_scal; o[1] = st_comp; o[2] = st_bwait; o[3] = st_bar;
+            if (cwv == 0) { o[16] = st_pro; o[17] = st_top; o[18] = st_mid; o[19] = st_acc; }
+        }
+#endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
     if (wave < kTileProducers) tile_producer_loop<KP, NBUF, BUF, CH>(a, ring, wring, dring, c0, nch, lane, wave);

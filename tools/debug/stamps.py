@@ -8,7 +8,8 @@ so = os.path.join(ROOT, "gpurun_out", "librgcn_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 abl = os.environ.get("RGCN_ABL", "0")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRGCN_STAMPS", "-DRGCN_ABL=" + abl,
-                os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_kernels.hip"), "-o", so], check=True)
+                os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_kernels.hip"),
+                os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_plan.hip"), "-o", so], check=True)
 from scaling_rgcn_training_amd import _lib
 _lib.LIB_PATH = so
 lib = _lib.load()
@@ -20,7 +21,8 @@ ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, 32, 64, 64, dev)
 _t, _c = P.choose_layout(n, e, 32, 64, 64)
 tile = int(os.environ.get("RGCN_TILE", _t))
 chunk = int(os.environ.get('RGCN_CHUNK', _c))
-plans = P.build_graph_plans(ei, et, n, 32, tile, chunk=chunk)
+split = os.environ.get('RGCN_SPLIT', '0') == '1'
+plans = P.build_graph_plans(ei, et, n, 32, tile, chunk=chunk, split=split)
 print("tile", tile)
 fp = plans.fwd
 stamps = torch.zeros(max(fp.n_tiles, 1024) * 32, dtype=torch.int64, device=dev)
@@ -48,7 +50,11 @@ names = ["cons scalar-loads", "cons compute", "cons B-wait", "cons barrier", "pr
 for i, nm in enumerate(names):
     print(f"{nm:20s} {s[:, i].sum() / nch.sum():9.1f} cycles/chunk")
 print(f"consumer loop total {tot_c.sum() / nch.sum():9.1f} cycles/chunk; producer wave0 loop total {tot_p.sum() / nch.sum():9.1f}")
-if which == "fwd":
+if split:
+    print("pair 1 (wave 6): scalar %.1f compute %.1f B-wait %.1f barrier %.1f cycles/chunk" % tuple(s[:, 8 + i].sum() / nch.sum() for i in range(4)))
+if split:
+    print("wave 4 fast path per chunk: prologue (first loads + split) %.1f | per-chunk sums over its tiles: top (acc addr, reads issued) %.1f  mid (split + MFMA) %.1f  accumulate (wait, FMA, store) %.1f" % tuple(s[:, 16 + i].sum() / nch.sum() for i in range(4)))
+if which == "fwd" and not split:
     for i in range(8):
         c = s[:, 16 + i].sum()
         print(f"chunks with {i + 1} row tiles: {int(c):9d}  compute {s[:, 8 + i].sum() / max(c, 1):8.1f} cycles/chunk")
