@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 9
+#define RGCN_ABI_VERSION 10
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -47,6 +47,7 @@ enum rgcn_act { RGCN_ACT_NONE = 0, RGCN_ACT_RELU = 1, RGCN_ACT_SIGMOID = 2 };
 #define RGCN_FLAG_POINTER_GATHER 1u /* address gathered rows with 64-bit pointers even where a buffer descriptor fits */
 #define RGCN_FLAG_DW_RING 2u        /* rgcn_bwd_dw: LDS-ring kernels whatever the size */
 #define RGCN_FLAG_DW_DIRECT 4u      /* rgcn_bwd_dw: direct-gather kernel whenever the widths allow (64 x 64) */
+#define RGCN_FLAG_DW_ROOT_ONLY 16u   /* rgcn_bwd_dw: d_root and d_bias only (the relations went to rgcn_bwd_dw_tiles) */
 #define RGCN_FLAG_EXACT_FP32 8u     /* rgcn_fwd / rgcn_bwd_dx: the exact-fp32 MFMA kernel also where the split-precision
                                      * (bf16 x 3, six products: fp32-equivalent) kernel applies: 64 x 64 on layout-1 plans */
 
@@ -195,6 +196,19 @@ size_t rgcn_bwd_dw_workspace_bytes(const rgcn_plan_t* plan, int din, int dout);
 int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const float* g, int ldg,
                 int dout, void* workspace, size_t workspace_bytes, float* d_weight, float* d_root,
                 float* d_bias, unsigned flags, void* stream);
+
+/* d_weight alone, tile-major (64 x 64 layers with at most 32 relations on large graphs): every wave owns one relation and
+ * keeps its 64 x 64 accumulator in registers for the whole launch, the upstream-gradient rows of a tile are staged in LDS
+ * once per relation quarter instead of being gathered per edge (37 GB instead of 55 GB moved at the headline config).
+ * `plan`: a FORWARD-direction plan built with the geometry rgcn_dw_tiles_geometry reports (tile = 304, chunk = 64, layout
+ * 0); walk_ptr: int32 [num_relations][walkers + 1], walk_ptr[r][p] = first position in plan->rel_order of relation r
+ * whose tile is >= p * n_tiles / walkers (integer division), walk_ptr[r][walkers] = end of relation r.
+ * d_root / d_bias: rgcn_bwd_dw(..., RGCN_FLAG_DW_ROOT_ONLY) on any forward plan of the same graph. */
+int rgcn_dw_tiles_geometry(int* tile, int* walkers, int* max_relations);
+size_t rgcn_bwd_dw_tiles_workspace_bytes(int num_relations);
+int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_ptr, const float* x, int ldx, int din, const float* g,
+                      int ldg, int dout, void* workspace, size_t workspace_bytes, float* d_weight, unsigned flags,
+                      void* stream);
 
 #ifdef __cplusplus
 }

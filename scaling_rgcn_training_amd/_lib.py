@@ -14,17 +14,18 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
     "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_act_backward", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
     "rgcn_plan_workspace_bytes", "rgcn_edge_weights", "rgcn_plan_build_begin", "rgcn_plan_build_finish",
+    "rgcn_dw_tiles_geometry", "rgcn_bwd_dw_tiles_workspace_bytes", "rgcn_bwd_dw_tiles",
 )
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT, FLAG_EXACT_FP32 = 1, 2, 4, 8
+FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT, FLAG_EXACT_FP32, FLAG_DW_ROOT_ONLY = 1, 2, 4, 8, 16
 
 
 class RgcnPlanStruct(C.Structure):
@@ -101,6 +102,12 @@ def load() -> C.CDLL:
                                           C.POINTER(RgcnPlanSizes), vp]
     lib.rgcn_plan_build_finish.restype = i32
     lib.rgcn_plan_build_finish.argtypes = [C.POINTER(RgcnPlanSizes), vp, sz, C.POINTER(RgcnPlanStruct), vp]
+    lib.rgcn_dw_tiles_geometry.restype = i32
+    lib.rgcn_dw_tiles_geometry.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rgcn_bwd_dw_tiles_workspace_bytes.restype = sz
+    lib.rgcn_bwd_dw_tiles_workspace_bytes.argtypes = [i32]
+    lib.rgcn_bwd_dw_tiles.restype = i32
+    lib.rgcn_bwd_dw_tiles.argtypes = [C.POINTER(RgcnPlanStruct), vp, vp, i32, i32, vp, i32, i32, vp, sz, vp, u32, vp]
     if lib.rgcn_abi_version() != ABI_VERSION:
         raise RgcnLibraryError(f"ABI version mismatch: library {lib.rgcn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
@@ -250,3 +257,20 @@ def plan_build(graph: RgcnGraphStruct, w: torch.Tensor, transposed: bool, node_b
         check(lib.rgcn_plan_build_finish(C.byref(sizes), ws.data_ptr(), ws.numel(), C.byref(ps), _stream(ws)),
               "rgcn_plan_build_finish")
     return ps, arr, int(sizes.n_edges)
+
+
+def dw_tiles_geometry():
+    """(tile, walkers, max relations) of the tile-major weight-gradient kernel"""
+    t, w, r = C.c_int(), C.c_int(), C.c_int()
+    check(load().rgcn_dw_tiles_geometry(C.byref(t), C.byref(w), C.byref(r)), "rgcn_dw_tiles_geometry")
+    return t.value, w.value, r.value
+
+
+def bwd_dw_tiles(ps: RgcnPlanStruct, walk_ptr: torch.Tensor, x: torch.Tensor, din: int, g: torch.Tensor, dout: int,
+                 d_weight: torch.Tensor, flags: int = 0) -> None:
+    lib = load()
+    nbytes = lib.rgcn_bwd_dw_tiles_workspace_bytes(int(ps.num_relations))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.rgcn_bwd_dw_tiles(C.byref(ps), walk_ptr.data_ptr(), x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0),
+                                    dout, ws.data_ptr(), nbytes, d_weight.data_ptr(), int(flags), _stream(x)), "rgcn_bwd_dw_tiles")

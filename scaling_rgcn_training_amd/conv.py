@@ -40,6 +40,7 @@ def _rows16(t: Tensor, width: int) -> Tensor:
 _ENV_TILE = int(os.environ["RGCN_TILE"]) if "RGCN_TILE" in os.environ else None
 _ENV_CHUNK = int(os.environ["RGCN_CHUNK"]) if "RGCN_CHUNK" in os.environ else None
 _SPLIT_PRECISION_DEFAULT = os.environ.get("RGCN_SPLIT_PRECISION", "0") == "1"
+DW_TILES_MIN_EDGES = 4_000_000
 
 _ACT_CODES = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID}
 
@@ -213,12 +214,19 @@ class _RGCNLayerFn(torch.autograd.Function):
 
             # ONE flat buffer for the three gradients: a single all-reduce in the distributed case
             acc = None
+            dwp = getattr(plans, "dw", None) if dctx is None else None
             for fp in fplans:
                 if fp.n_owned <= 0:
                     continue
                 part = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
                 pw, pr, pb = views(part)
-                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb, flags)
+                if dwp is not None and need_w and not (flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)):
+                    # relations: tile-major kernel (gradient rows staged in LDS); root + bias: relation-major walk of the root units
+                    _lib.bwd_dw_tiles(_lib.plan_struct(dwp), plans.dw_walk, xp, din, gp, dout, pw, flags)
+                    if need_root or need_bias:
+                        _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp, dout, None, pr, pb, flags | _lib.FLAG_DW_ROOT_ONLY)
+                else:
+                    _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb, flags)
                 acc = part if acc is None else acc.add_(part)
             if acc is None:
                 acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -288,6 +296,7 @@ class RGCNConv(nn.Module):
         # where it exists (64 x 64, dense groups).  Off by default: measured no faster than the exact-fp32 kernel
         # (10.9 vs 10.6 ms per launch at the headline config).
         self.split_precision = _SPLIT_PRECISION_DEFAULT
+        self.dw_tiles = True      # d_weight by the tile-major kernel where it applies (_plans); False: relation-major kernels
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
             self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
@@ -343,7 +352,12 @@ class RGCNConv(nn.Module):
         tile, chunk = layout_for(self.in_channels, self.out_channels, n, e, self.num_relations)
         split = self.split_precision and split_for(self.in_channels, self.out_channels, n, e, self.num_relations, tile, chunk)
         if self.dist is None:
-            return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split)
+            # the tile-major weight-gradient kernel: 64 x 64 layers with few relations on graphs large enough to fill it
+            from .plan import padded_width
+            dw_tiles = (self.dw_tiles and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64
+                        and self.num_relations <= 32 and e >= DW_TILES_MIN_EDGES and x.is_cuda)
+            return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split,
+                                      dw_tiles=dw_tiles)
         from .dist import cached_rank_plans
         return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split)
 

@@ -2052,6 +2052,189 @@ __global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) 
     if (rel_cur >= 0) flush();
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel, tile-major form (64 x 64, at most 32 relations, buffer-addressable operands)
+// ------------------------------------------------------------------------------------------------
+// The relation-major kernels above gather TWO rows per slot -- x[src] and the upstream gradient g[dst] -- although only
+// N gradient rows exist: E * 4 * out bytes of gathers (25.6 GB at the headline config) that no walk ORDER gets the caches
+// to serve.  Making the reuse structural means staging a tile's gradient rows in LDS and walking
+// tile-major -- and then the relation changes with every (tile, relation) group, which is why the accumulators have to be
+// somewhere that survives the whole walk.  Here they are: a wave owns ONE relation for the whole launch and keeps its
+// 64 x 64 accumulator in registers (64 VGPRs, as in the direct kernel); a workgroup = 8 waves = 8 relations, FOUR
+// workgroups (relation quarters) share a tile range, `walkers` ranges cover the graph.  Per tile: the workgroup's waves
+// DMA the tile's T = 304 gradient rows into one of two LDS buffers (2 x 76 KiB) a tile ahead, each wave walks the
+// 64-slot units of (tile, its relation) -- a contiguous stretch of rel_order -- loading x rows straight from global
+// memory into registers half a unit ahead (rgcn_dw_direct_kernel's pipeline) and reading the gradient rows from LDS.
+// Traffic: x gathers E * 4 * in + four sweeps of g (4 N * 4 * out) + indices = 37 GB instead of 55; one barrier per tile.
+// The root relation and the bias gradient stay with rgcn_dw_direct_kernel (RGCN_FLAG_DW_ROOT_ONLY): their x rows are
+// the tile's own.
+constexpr int kDwTileT = 304;                    // gradient rows per LDS buffer = tile size of the plan this kernel walks
+constexpr int kDwTileWalkers = 64;               // tile ranges; x 4 relation quarters = 256 workgroups, one per CU
+constexpr int kDwTileMaxRel = 32;
+
+struct DwTileArgs {
+    const int* rel_order;   // of a plan with tile = kDwTileT, 64-slot chunks (unit == chunk), layout 0
+    const int* chunk_cnt;
+    const int* chunk_tile;
+    const int* slot_src;
+    const float* slot_w;
+    const int* slot_row;
+    const int* walk_ptr;    // [num_rel][walkers + 1]: rel_order positions where walker p's tiles of relation r begin
+    const float* x;
+    const float* g;
+    unsigned x_bytes, g_bytes;
+    float* slabs;           // [walkers][num_rel][64 * 64]
+    int ldx, ldg, dout4, n_tiles, n_owned, num_rel, walkers;
+};
+
+__global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a) {
+    constexpr int T = kDwTileT, NP = 64, HS = 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][T][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quarter = blockIdx.x & 3, p = blockIdx.x >> 2;
+    const int rel = 8 * quarter + wave;
+    const bool have = rel < a.num_rel;
+    const int t0 = (int)((long)p * a.n_tiles / a.walkers), t1 = (int)((long)(p + 1) * a.n_tiles / a.walkers);
+    if (t1 <= t0) return;
+    const int i0 = have ? ldc(a.walk_ptr, (long)rel * (a.walkers + 1) + p) : 0;
+    const int nun = have ? ldc(a.walk_ptr, (long)rel * (a.walkers + 1) + p + 1) - i0 : 0;
+    const int ml = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rg = make_rsrc(a.g, a.g_bytes);
+    const unsigned colb = 16u * (unsigned)ml;
+    const unsigned rbx = (unsigned)a.ldx * 4u, rbg = (unsigned)a.ldg * 4u;
+    const unsigned gcol = ml < a.dout4 ? colb : 0xFFFFFFF0u;     // columns beyond the width: out of range -> zeros
+    const unsigned grow = ml < a.dout4 ? rbg : 0u;
+    const int perm = kq * 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ia][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // tile t -> LDS buffer b: DMA instruction i moves rows 4 i .. 4 i + 3 (64 lanes x 16 bytes); rows past the end read zeros
+    auto dma_tile = [&](int t, int b) {
+        float* base = lds + b * T * NP;
+        for (int i = wave; i < T / 4; i += 8) {
+            const unsigned row = (unsigned)(t * T + 4 * i + kq);
+            dma16_buf(rg, __umul24(row, grow) + gcol, base + i * 4 * NP);
+        }
+    };
+    struct Idx {      // lane l: slot l of the unit
+        int h, g;
+        float w;
+    };
+    auto unit_of = [&](int k) { return ldc(a.rel_order, i0 + (k < nun ? k : (nun > 0 ? nun - 1 : 0))); };
+    auto load_idx = [&](int unit) {
+        const size_t base = (size_t)unit * kChunk + lane;
+        return Idx{a.slot_src[base], a.slot_row[base], a.slot_w[base]};
+    };
+    auto issue_half = [&](f32x4 (&a4)[HS], const Idx& ix, int h) {
+        int ih[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) ih[s] = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), ix.h);
+#pragma unroll
+        for (int s = 0; s < HS; ++s)
+            a4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)ih[s], rbx) + colb), 0, 0));
+    };
+    // half a unit: 8 k-steps of 4 rows; gradient rows from the LDS tile (row ids local to the tile, padding clamped: its
+    // weight is 0 and every LDS word is a finite number)
+    auto compute_half = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {
+        const unsigned loc = (unsigned)(ix.g - tile_row0);
+        const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));    // byte offset of this lane's slot row
+        float wv[HS];
+        f32x4 g4[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            wv[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), __builtin_bit_cast(int, ix.w)));
+            const int o = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), goff);
+            g4[s] = *(const f32x4*)((const char*)gbuf + o + colb);
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            if (2 * h + gi < ngrp) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int s = 4 * gi + t;
+                    f32x4 bv = g4[s] * wv[s];
+                    asm volatile("s_nop 4" : "+v"(bv));       // VALU write -> asm MFMA operand (see rgcn_dw_direct_kernel)
+#pragma unroll
+                    for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb)
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[ia][jb]) : "v"(a4[s][ia]), "v"(bv[jb]));
+                }
+            }
+        }
+    };
+
+    dma_tile(t0, 0);
+    int k = 0;
+    int uid_cur = unit_of(0), uid_nxt = unit_of(1), uid_nn = unit_of(2);
+    int cnt_cur = ldc(a.chunk_cnt, uid_cur), tile_cur = nun > 0 ? ldc(a.chunk_tile, uid_cur) : t1;
+    int cnt_nxt = ldc(a.chunk_cnt, uid_nxt), tile_nxt = nun > 1 ? ldc(a.chunk_tile, uid_nxt) : t1;
+    Idx ix_cur = load_idx(uid_cur), ix_nxt = load_idx(uid_nxt);
+    f32x4 s0[HS], s1[HS];
+    if (nun > 0) issue_half(s0, ix_cur, 0);
+    for (int t = t0; t < t1; ++t) {
+        // The DMAs of tile t were issued a tile ago (or in the prologue), before every x load of the units walked since; at
+        // most 11 younger operations are in flight at a unit boundary (8 row loads + 3 index loads of the unit after next).
+        asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        wg_barrier();          // tile t landed for every wave; every wave is done with the buffer tile t + 1 goes to
+        const int b = (t - t0) & 1;
+        if (t + 1 < t1) dma_tile(t + 1, b ^ 1);
+        const float* gbuf = lds + b * T * NP;
+        while (k < nun && tile_cur == t) {
+            const int ngrp = (cnt_cur + 15) >> 4;
+            issue_half(s1, ix_cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_half(s0, ix_cur, 0, ngrp, gbuf, t * T);
+            __builtin_amdgcn_sched_barrier(0);
+            const Idx ix_nn = load_idx(uid_nn);
+            issue_half(s0, ix_nxt, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_half(s1, ix_cur, 1, ngrp, gbuf, t * T);
+            __builtin_amdgcn_sched_barrier(0);
+            ++k;
+            ix_cur = ix_nxt;
+            ix_nxt = ix_nn;
+            uid_cur = uid_nxt;
+            uid_nxt = uid_nn;
+            uid_nn = unit_of(k + 2);
+            cnt_cur = cnt_nxt;
+            tile_cur = k < nun ? tile_nxt : t1;
+            cnt_nxt = ldc(a.chunk_cnt, uid_nxt);
+            tile_nxt = k + 1 < nun ? ldc(a.chunk_tile, uid_nxt) : t1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the accumulators are read by plain stores the compiler schedules: keep them clear of the last asm MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (have) {
+        float* slab = a.slabs + ((size_t)p * a.num_rel + rel) * (64 * 64);
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(4 * (4 * kq + r) + ia) * NP + 4 * ml + jb] = acc[ia][jb][r];
+    }
+}
+
+// d_weight[r] = sum over the walkers' slabs, in walker order (bitwise reproducible)
+__global__ void rgcn_dw_tile_reduce_kernel(const float* __restrict__ slabs, int walkers, int num_rel, int din, int dout,
+                                           float* __restrict__ d_weight) {
+    const int r = blockIdx.x;
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < din * dout; e += gridDim.y * blockDim.x) {
+        const int kk = e / dout, n = e - kk * dout;
+        float sum = 0.f;
+        for (int w = 0; w < walkers; ++w) sum += slabs[((size_t)w * num_rel + r) * (64 * 64) + kk * 64 + n];
+        d_weight[(size_t)r * din * dout + e] = sum;
+    }
+}
+
 // slabs -> gradients, fixed summation order (block index ascending) => bitwise reproducible.
 // grid = (R' + 2, parts): blockIdx.x = relation (R' = root, R'+1 = bias), blockIdx.y = slice of the elements.
 // The workgroups whose chunk range touches relation r are a contiguous run [b_lo, b_hi].
@@ -2444,22 +2627,38 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     if ((st = check_device()) != RGCN_OK) return st;
     const int KP = padded_width(din), NP = padded_width(dout);
     hipStream_t s = (hipStream_t)stream;
+    // RGCN_FLAG_DW_ROOT_ONLY: d_root / d_bias alone (the relations went to rgcn_bwd_dw_tiles): walk the root relation's
+    // units, which close rel_order -- their count follows from the tile geometry (every node has one root pseudo edge)
+    int unit_begin = 0, n_units = plan->n_units;
+    if (flags & RGCN_FLAG_DW_ROOT_ONLY) {
+        auto units_of = [&](long rows) -> long {
+            if (plan->layout == 0 || plan->chunk == 64) return ((rows + 15) / 16 + 3) / 4;
+            const long rem = rows % 128;
+            return 2 * (rows / 128) + (rem == 0 ? 0 : (rem > 64 ? 2 : 1));
+        };
+        const long last_rows = (long)plan->n_owned - (long)(plan->n_tiles - 1) * plan->tile;
+        const long root_units = (long)(plan->n_tiles - 1) * units_of(plan->tile) + units_of(last_rows);
+        if (root_units <= 0 || root_units > n_units) return RGCN_ERR_PLAN;
+        unit_begin = n_units - (int)root_units;
+        n_units = (int)root_units;
+        d_weight = nullptr;
+    }
     // The direct-gather kernel (64 x 64, buffer-addressable operands) pays on large walks; small graphs take fewer
     // persistent workgroups (>= 16 units each) of the ring kernels, and only their slabs are cleared / summed.
     // RGCN_FLAG_DW_RING / RGCN_FLAG_DW_DIRECT pin the choice (tests exercise both on small graphs).
     const unsigned xb = buffer_bytes(plan->n_nodes, ldx, flags), gb = buffer_bytes(plan->n_owned, ldg, flags);
     const bool can_direct = KP == 64 && NP == 64 && xb != 0 && gb != 0;
     const bool want_direct = can_direct && !(flags & RGCN_FLAG_DW_RING) &&
-                             ((flags & RGCN_FLAG_DW_DIRECT) || plan->n_units >= kDwDirectMinUnits);
+                             ((flags & RGCN_FLAG_DW_DIRECT) || n_units >= kDwDirectMinUnits);
     const int max_blocks = want_direct ? kDwBlocks : kDwRingBlocks;
-    const int nblocks = plan->n_units / 16 < 1 ? 1 : (plan->n_units / 16 > max_blocks ? max_blocks : plan->n_units / 16);
+    const int nblocks = n_units / 16 < 1 ? 1 : (n_units / 16 > max_blocks ? max_blocks : n_units / 16);
     const size_t slab_bytes = sizeof(float) * (size_t)(nblocks + plan->num_relations + 1) * kDwSlabsPer * KP * NP;
     float* bias_slabs = (float*)workspace + dw_slab_floats(plan->num_relations, KP, NP);
     hipError_t e = hipMemsetAsync(workspace, 0, slab_bytes, s);
     if (e == hipSuccess) e = hipMemsetAsync(bias_slabs, 0, sizeof(float) * (size_t)nblocks * kDwSlabsPer * NP, s);
     if (e != hipSuccess) return (int)e;
     DwArgs a;
-    a.rel_order = plan->rel_order;
+    a.rel_order = plan->rel_order + unit_begin;
     a.chunk_rel = plan->chunk_rel;
     a.chunk_cnt = plan->chunk_cnt;
     a.chunk_tile = plan->chunk_tile;
@@ -2479,7 +2678,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     a.ldg = ldg;
     a.dout4 = (dout + 3) / 4;
     a.tile = plan->tile;
-    a.n_units = plan->n_units;
+    a.n_units = n_units;
     a.ushift = plan->chunk == 128 ? 1 : 0;
     a.num_rel = plan->num_relations;
     if (want_direct) {
@@ -2490,7 +2689,65 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     }
     if (st != RGCN_OK) return st;
     hipLaunchKernelGGL(rgcn_dw_reduce_kernel, dim3(plan->num_relations + 2, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs, a.bias_slabs,
-                       plan->rel_order, plan->chunk_rel, plan->n_units, a.ushift, nblocks, plan->num_relations, KP, NP, din,
+                       a.rel_order, plan->chunk_rel, n_units, a.ushift, nblocks, plan->num_relations, KP, NP, din,
                        dout, d_weight, d_root, d_bias);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rgcn_dw_tiles_geometry(int* tile, int* walkers, int* max_relations) {
+    if (tile) *tile = kDwTileT;
+    if (walkers) *walkers = kDwTileWalkers;
+    if (max_relations) *max_relations = kDwTileMaxRel;
+    return RGCN_OK;
+}
+
+extern "C" size_t rgcn_bwd_dw_tiles_workspace_bytes(int num_relations) {
+    return num_relations > 0 ? sizeof(float) * (size_t)kDwTileWalkers * num_relations * 64 * 64 : 0;
+}
+
+extern "C" int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_ptr, const float* x, int ldx, int din, const float* g,
+                                 int ldg, int dout, void* workspace, size_t workspace_bytes, float* d_weight, unsigned flags,
+                                 void* stream) {
+    int st = check_plan(plan);
+    if (st != RGCN_OK) return st;
+    if (!walk_ptr || !x || !g || !workspace || !d_weight) return RGCN_ERR_NULL;
+    if ((st = check_stride(ldx, din)) != RGCN_OK) return st;
+    if ((st = check_stride(ldg, dout)) != RGCN_OK) return st;
+    if (padded_width(din) != 64 || padded_width(dout) != 64) return RGCN_ERR_WIDTH;
+    if (plan->tile != kDwTileT || plan->chunk != 64 || plan->layout != 0 || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
+    if (workspace_bytes < rgcn_bwd_dw_tiles_workspace_bytes(plan->num_relations)) return RGCN_ERR_WORKSPACE;
+    if ((st = check_device()) != RGCN_OK) return st;
+    DwTileArgs a;
+    a.rel_order = plan->rel_order;
+    a.chunk_cnt = plan->chunk_cnt;
+    a.chunk_tile = plan->chunk_tile;
+    a.slot_src = plan->slot_src;
+    a.slot_w = plan->slot_w;
+    a.slot_row = plan->slot_row;
+    a.walk_ptr = walk_ptr;
+    a.x = x;
+    a.g = g;
+    a.x_bytes = buffer_bytes(plan->n_nodes, ldx, flags);
+    a.g_bytes = buffer_bytes(plan->n_owned, ldg, flags);
+    if (a.x_bytes == 0 || a.g_bytes == 0) return RGCN_ERR_PLAN;       // this kernel addresses through buffer descriptors only
+    a.slabs = (float*)workspace;
+    a.ldx = ldx;
+    a.ldg = ldg;
+    a.dout4 = (dout + 3) / 4;
+    a.n_tiles = plan->n_tiles;
+    a.n_owned = plan->n_owned;
+    a.num_rel = plan->num_relations;
+    a.walkers = kDwTileWalkers;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = sizeof(float) * 2 * kDwTileT * 64;
+    hipError_t e = allow_full_lds<rgcn_dw_tile_kernel>();
+    if (e != hipSuccess) return (int)e;
+    // walkers without tiles leave their slabs untouched: clear what the reduction reads
+    e = hipMemsetAsync(workspace, 0, rgcn_bwd_dw_tiles_workspace_bytes(plan->num_relations), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(rgcn_dw_tile_kernel, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+    if ((st = (int)hipGetLastError()) != 0) return st;
+    hipLaunchKernelGGL(rgcn_dw_tile_reduce_kernel, dim3(plan->num_relations, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs,
+                       kDwTileWalkers, plan->num_relations, din, dout, d_weight);
     return (int)hipGetLastError();
 }

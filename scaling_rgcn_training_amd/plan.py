@@ -402,6 +402,8 @@ class GraphPlans:
     fwd: TilePlan
     bwd: TilePlan
     num_edges: int
+    dw: Optional[TilePlan] = None        # forward-direction plan in the geometry of the tile-major dW kernel (dw_walk_table)
+    dw_walk: Optional[Tensor] = None     # int32 [R'][walkers + 1]
 
 
 def build_graph_plans_torch(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
@@ -440,7 +442,7 @@ def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, t
 def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
                              aggr: str = "mean", fwd_range: Optional[Tuple[int, int]] = None,
                              bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
-                             ranges=None, split: bool = False):
+                             ranges=None, split: bool = False, dw_tiles: bool = False):
     """The plans built by the HIP library itself (csrc/rgcn_plan.hip through rgcn_edge_weights / rgcn_plan_build_*):
     what every GPU forward uses.  ``ranges``: a list of (begin, end) owned ranges -> a list of GraphPlans that share one
     edge-weight pass and one workspace (dist.py: one pair of plans per owned block)."""
@@ -462,20 +464,38 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
     for (fb, fe), (bb, be) in rs:
         fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws, split)
         bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
-        out.append(GraphPlans(fwd=fwd, bwd=bwd, num_edges=fwd.n_edges if ranges is not None else e))
+        gp = GraphPlans(fwd=fwd, bwd=bwd, num_edges=fwd.n_edges if ranges is not None else e)
+        if dw_tiles and ranges is None and (fb, fe) == (0, n_nodes):
+            t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
+            if num_relations <= max_rel:
+                gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, 0, n_nodes, ws, False)
+                gp.dw_walk = dw_walk_table(gp.dw, walkers)
+        out.append(gp)
     del keep
     return out if ranges is not None else out[0]
+
+
+def dw_walk_table(plan: TilePlan, walkers: int) -> Tensor:
+    """walk_ptr of rgcn_bwd_dw_tiles: for relation r and walker p the first position in ``plan.rel_order`` (sorted by
+    (relation, tile)) of a unit of relation r whose tile is >= p * n_tiles // walkers; column ``walkers`` = end of relation r."""
+    dev = plan.rel_order.device
+    units = plan.rel_order.long()
+    upc = plan.chunk // UNIT
+    key = plan.chunk_rel.long()[units // upc] * plan.n_tiles + plan.chunk_tile.long()[units // upc]
+    r = torch.arange(plan.num_relations, device=dev)[:, None]
+    t = (torch.arange(walkers + 1, device=dev) * plan.n_tiles // walkers)[None, :]
+    return torch.searchsorted(key, (r * plan.n_tiles + t).reshape(-1)).view(plan.num_relations, walkers + 1).to(torch.int32).contiguous()
 
 
 def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
                       tile: int, aggr: str = "mean",
                       fwd_range: Optional[Tuple[int, int]] = None,
                       bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
-                      split: bool = False) -> GraphPlans:
+                      split: bool = False, dw_tiles: bool = False) -> GraphPlans:
     """Device tensors: the HIP plan builder behind the C ABI.  CPU tensors (tests without a GPU): the torch form."""
     if edge_type.device.type == "cuda" and _WALK_MODE == "sorted":
         return build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk,
-                                        split=split)
+                                        split=split, dw_tiles=dw_tiles)
     return build_graph_plans_torch(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk, split)
 
 
@@ -506,21 +526,23 @@ _CACHE_MAX_BYTES = int(float(_os.environ.get("RGCN_PLAN_CACHE_GB", "48")) * (1 <
 
 def _plans_nbytes(plans) -> int:
     pieces = getattr(plans, "pieces", None) or [plans]
-    return sum(p.fwd.nbytes() + p.bwd.nbytes() for p in pieces)
+    return sum(p.fwd.nbytes() + p.bwd.nbytes() + (p.dw.nbytes() if getattr(p, "dw", None) is not None else 0) for p in pieces)
 
 
 def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
-                       tile: int, aggr: str, builder=None, extra_key=(), chunk: int = CHUNK, split: bool = False) -> GraphPlans:
+                       tile: int, aggr: str, builder=None, extra_key=(), chunk: int = CHUNK, split: bool = False,
+                       dw_tiles: bool = False) -> GraphPlans:
     """LRU over (edge tensors' identity, layout): at most ``_CACHE_MAX`` entries and ``RGCN_PLAN_CACHE_GB`` (48) GiB of
     plan arrays (4.3 GB per 100M edges), least recently used evicted first."""
     key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
-           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr, bool(split)) + tuple(extra_key)
+           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr, bool(split), bool(dw_tiles)) + tuple(extra_key)
     hit = _CACHE.pop(key, None)
     if hit is not None:
         _CACHE[key] = hit           # most recently used last
         return hit[0]
     if builder is None:
-        plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split)
+        plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split,
+                                  dw_tiles=dw_tiles)
     else:
         plans = builder()
     nbytes = _plans_nbytes(plans)

@@ -399,3 +399,43 @@ def test_split_precision_kernel_matches_oracle(dev, n, e, r, tile, skew):
     for a, b in zip(res3[:2], res1[:2]):
         assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, float(np.abs(b).max()))
     assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel
+
+
+@pytest.mark.parametrize("n,e,r,skew", [(5000, 90000, 7, False), (20000, 600000, 32, False), (3000, 200000, 3, True), (700, 5000, 32, False)])
+def test_dw_tile_major_kernel(dev, n, e, r, skew):
+    """rgcn_bwd_dw_tiles (tile-major d_weight: one relation per wave, gradient rows staged in LDS) + the root-only walk of
+    rgcn_bwd_dw against the oracle, and against the relation-major kernels on the same inputs."""
+    from scaling_rgcn_training_amd import _lib, plan as P
+    din = dout = 64
+    ei, et = O.synthetic_graph(n, e, r, seed=n + r, skew=skew)
+    if r > 2:
+        et = et.clamp(max=r - 2)                 # dead last relation
+    ei[:, 10:60] = ei[:, 70:120]                 # duplicate triples
+    et[10:60] = et[70:120]
+    w, root, bias = O.synthetic_params(r, din, dout, seed=2)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
+    assert r <= max_rel
+    plans = P.build_graph_plans_device(ei.to(dev), et.to(dev), n, r, 128, dw_tiles=True)
+    assert plans.dw is not None and plans.dw.tile == t_dw and plans.dw.chunk == 64 and plans.dw_walk.shape == (r, walkers + 1)
+    xd, gd = x.to(dev), dg.to(dev)
+    dw = torch.full((r, din, dout), float("nan"), device=dev)
+    _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, xd, din, gd, dout, dw)
+    dr = torch.full((din, dout), float("nan"), device=dev)
+    db = torch.full((dout,), float("nan"), device=dev)
+    _lib.bwd_dw(_lib.plan_struct(plans.fwd), xd, din, gd, dout, None, dr, db, _lib.FLAG_DW_ROOT_ONLY)
+    dw0, dr0, db0 = torch.empty_like(dw), torch.empty_like(dr), torch.empty_like(db)
+    _lib.bwd_dw(_lib.plan_struct(plans.fwd), xd, din, gd, dout, dw0, dr0, db0)
+    torch.cuda.synchronize()
+    c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
+    _, g32 = cpu32_reference(x, ei, et, w, root, bias, dg)
+    assert_close(dw.cpu().numpy(), gr["weight"], c["weight"], f"d_weight (tile-major) [n{n} r{r}]", cpu32=g32["weight"])
+    assert_close(dr.cpu().numpy(), gr["root"], c["root"], f"d_root (root-only walk) [n{n} r{r}]", cpu32=g32["root"])
+    assert_close(db.cpu().numpy(), gr["bias"], c["bias"], f"d_bias (root-only walk) [n{n} r{r}]", cpu32=g32["bias"])
+    assert_close(dw.cpu().numpy(), dw0.cpu().numpy(), c["weight"], "tile-major vs relation-major d_weight")
+    assert torch.equal(dr, dr0) and torch.equal(db, db0), "the root-only walk is the same walk of the same units"
+    if r > 2:
+        assert torch.all(dw[r - 1] == 0)
