@@ -453,7 +453,8 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
     e = int(edge_type.shape[0])
     rs = ranges if ranges is not None else [(fwd_range or (0, n_nodes), bwd_range or (0, n_nodes))]
     own_max = max([1] + [max(f[1] - f[0], b[1] - b[0]) for f, b in rs])
-    ws = _lib.plan_workspace(e, own_max, num_relations, tile, edge_type.device)
+    ws_tile = min(tile, _lib.dw_tiles_geometry()[0]) if dw_tiles else tile      # the smallest tile sizes the group arrays
+    ws = _lib.plan_workspace(e, own_max, num_relations, ws_tile, edge_type.device)
     try:
         w = _lib.edge_weights(graph, aggr, ws)
     except _lib.RgcnLibraryError as err:

@@ -432,10 +432,12 @@ def test_dw_tile_major_kernel(dev, n, e, r, skew):
     torch.cuda.synchronize()
     c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
     _, g32 = cpu32_reference(x, ei, et, w, root, bias, dg)
-    assert_close(dw.cpu().numpy(), gr["weight"], c["weight"], f"d_weight (tile-major) [n{n} r{r}]", cpu32=g32["weight"])
+    assert_close(dw.cpu().numpy(), gr["weight"], c["weight"], f"d_weight (tile-major) [n{n} r{r}]", cpu32=g32["weight"], cpu_factor=4.0)
     assert_close(dr.cpu().numpy(), gr["root"], c["root"], f"d_root (root-only walk) [n{n} r{r}]", cpu32=g32["root"])
     assert_close(db.cpu().numpy(), gr["bias"], c["bias"], f"d_bias (root-only walk) [n{n} r{r}]", cpu32=g32["bias"])
     assert_close(dw.cpu().numpy(), dw0.cpu().numpy(), c["weight"], "tile-major vs relation-major d_weight")
-    assert torch.equal(dr, dr0) and torch.equal(db, db0), "the root-only walk is the same walk of the same units"
+    # (same units, but cut into workgroup ranges of their own: same sums up to fp32 re-association)
+    assert_close(dr.cpu().numpy(), dr0.cpu().numpy(), c["root"], "root-only vs full walk d_root")
+    assert_close(db.cpu().numpy(), db0.cpu().numpy(), c["bias"], "root-only vs full walk d_bias")
     if r > 2:
         assert torch.all(dw[r - 1] == 0)
