@@ -256,6 +256,9 @@ struct TileArgs {
     int ldm;
     int act;            // forward only: RGCN_ACT_* applied in the tile store
     int dbg;            // diagnostic builds only (RGCN_DBG)
+    int n_tiles;        // tiles of the plan
+    int tiles_per_wg;   // consecutive tiles one workgroup walks (rgcn_tile_kernel): the next tile's first gathers are in
+                        // flight while the finished tile is stored
 };
 
 // accumulator row stride of the tile kernel's LDS tile (floats)
@@ -277,10 +280,22 @@ constexpr int kTileProducers = RGCN_TILE_PW;
 constexpr int kTileThreads = 64 * (kTileProducers + 4);
 
 // ---- producers of the forward / dX kernels: LDS-DMA gather, D chunks ahead of the consumers -----------------------
+// c0 / nch: the chunks of ALL the tiles the workgroup walks (one sequence); tile0: its first tile.  Where a chunk closes a
+// tile the consumers store and re-initialise the accumulator between two extra barriers' worth of time: the producers
+// join that one extra barrier (E) so that the barrier counts of the two roles stay equal.
 template <int KP, int NBUF, bool BUF, int CH>
 __device__ __forceinline__ void tile_producer_loop(const TileArgs& a, float* ring, float* wring, int* dring, int c0, int nch,
-                                                   int lane, int wave) {
+                                                   int lane, int wave, int tile0) {
     constexpr int D = NBUF - 1;
+    int tile_cur = tile0;
+    int tend = ldc(a.tile_ptr, tile0 + 1) - c0;        // first chunk (relative) of the next tile
+    auto tile_boundary = [&](int it) {                  // after the barrier that closes chunk `it`
+        if (it + 1 == tend && it + 1 < nch) {
+            ++tile_cur;
+            tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
+            wg_barrier();
+        }
+    };
         // The producers' few instructions must not queue behind the consumer wave's MFMAs on the shared SIMD
         // (issue is arbitrated by priority, then age; an fp32 MFMA holds the pipe 32 cycles): RGCN_PRIO
         __builtin_amdgcn_s_setprio(RGCN_PRIO);
@@ -337,6 +352,7 @@ __device__ __forceinline__ void tile_producer_loop(const TileArgs& a, float* rin
                 STAMP_ADD(sp_issue, p0, p1);
                 STAMP_ADD(sp_wait, p1, p2);
                 STAMP_ADD(sp_bar, p2, p3);
+                tile_boundary(it);
             }
         } else {
         // Row indices of this wave's NEXT chunk: one coalesced load, issued right after the current
@@ -383,6 +399,7 @@ __device__ __forceinline__ void tile_producer_loop(const TileArgs& a, float* rin
             STAMP_ADD(sp_issue, p0, p1);
             STAMP_ADD(sp_wait, p1, p2);
             STAMP_ADD(sp_bar, p2, p3);
+            tile_boundary(it);
         }
         }
         wait_vmcnt<0>();
@@ -396,8 +413,11 @@ __device__ __forceinline__ void tile_producer_loop(const TileArgs& a, float* rin
 }
 
 // ---- epilogue of the forward / dX kernels: the finished tile, whole 16-byte pieces, coalesced ------------------------
-template <int LDO>
-__device__ __forceinline__ void tile_epilogue(const TileArgs& a, const float* out_lds, int tile, int tid) {
+// REINIT: every element is also reset to the bias for the NEXT tile of a workgroup that walks several tiles (each thread
+// resets exactly the elements it has just read; columns beyond the width never leave zero, the dummy row is never stored).
+// tid / nthreads: the calling threads' rank and count (all 512, or the 256 consumer threads between two tiles).
+template <int LDO, bool REINIT>
+__device__ __forceinline__ void tile_epilogue(const TileArgs& a, float* out_lds, int tile, int tid, int nthreads) {
     const int row0 = tile * a.tile;
     const int rows = min(a.tile, a.n_owned - row0);
     const int o4 = (a.dout + 3) >> 2;
@@ -406,9 +426,23 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, const float* ou
     // NEXT layer the ReLU backward of this layer's output is the mask (input > 0) on the stored gradient rows.
     // Padding columns (dout .. 4 * o4) stay zero: relu(0) = 0, and sigmoid is applied to real columns only.
     const int act = a.act;
-    for (int i = tid; i < rows * o4; i += kTileThreads) {
+    auto bias4 = [&](int c4) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = c4 * 4 + c < a.dout ? a.bias[c4 * 4 + c] : 0.f;
+        }
+        return b;
+    };
+    // a thread meets one column group only when the thread count is a multiple of the groups per row: its bias then
+    // is loaded once, not per element
+    const bool fixed_c4 = REINIT && (nthreads % o4) == 0;
+    f32x4 bfix = {0.f, 0.f, 0.f, 0.f};
+    if (fixed_c4) bfix = bias4(tid % o4);
+    for (int i = tid; i < rows * o4; i += nthreads) {
         const int r = i / o4, c4 = i - r * o4;
         f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
+        if constexpr (REINIT) *(f32x4*)(out_lds + r * LDO + c4 * 4) = fixed_c4 ? bfix : bias4(c4);
         if (act == RGCN_ACT_RELU) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : 0.f;
@@ -447,9 +481,12 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
-    const int c0 = ldc(a.tile_ptr, tile);
-    const int nch = ldc(a.tile_ptr, tile + 1) - c0;
+    // a workgroup walks `tiles_per_wg` consecutive tiles: their chunks form ONE sequence for the ring, and between two
+    // tiles only the accumulator is stored and reset -- the next tile's first chunk is already in LDS by then
+    const int tile0 = blockIdx.x * a.tiles_per_wg;
+    const int tile1 = min(tile0 + a.tiles_per_wg, a.n_tiles);
+    const int c0 = ldc(a.tile_ptr, tile0);
+    const int nch = ldc(a.tile_ptr, tile1) - c0;
 
     for (int i = tid; i < (a.tile + 1) * LDO; i += kTileThreads) {
         const int col = i % LDO;
@@ -517,6 +554,8 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             prefetch_rel(rel_n1);
             pending = true;
         }
+        int tile_cur = tile0;
+        int tend = ldc(a.tile_ptr, tile0 + 1) - c0;     // first chunk (relative) of the next tile
         wg_barrier();
 #ifdef RGCN_STAMPS
         unsigned long long st_scal = 0, st_comp = 0, st_bwait = 0, st_bar = 0;
@@ -828,6 +867,14 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             STAMP(t3);
             wg_barrier();
             STAMP(t4);
+            if (it + 1 == tend && it + 1 < nch) {
+                // this chunk closed a tile: store it and reset the accumulator (the 256 consumer threads; the producers
+                // wait at the same extra barrier with the next tile's first chunk landed and the second one on its way)
+                tile_epilogue<LDO, true>(a, out_lds, tile_cur, tid - 64 * kTileProducers, kTileThreads - 64 * kTileProducers);
+                ++tile_cur;
+                tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
+                wg_barrier();
+            }
             STAMP_ADD(st_scal, t0, t1);
             STAMP_ADD(st_comp, t1, t2);
             STAMP_ADD(st_bwait, t2, t3);
@@ -852,8 +899,8 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
         // order) reuses these registers; otherwise it waits vmcnt(0) between the prologue DMAs
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
-    if (wave < kTileProducers) tile_producer_loop<KP, NBUF, BUF, CH>(a, ring, wring, dring, c0, nch, lane, wave);
-    tile_epilogue<LDO>(a, out_lds, tile, tid);
+    if (wave < kTileProducers) tile_producer_loop<KP, NBUF, BUF, CH>(a, ring, wring, dring, c0, nch, lane, wave, tile0);
+    tile_epilogue<LDO, false>(a, out_lds, tile1 - 1, tid, kTileThreads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1302,8 +1349,8 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile3_kern
 #endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rgcn_tile_kernel
     }
-    if (wave < kTileProducers) tile_producer_loop<KP, NBUF, BUF, CH>(a, ring, wring, dring, c0, nch, lane, wave);
-    tile_epilogue<LDO>(a, out_lds, tile, tid);
+    if (wave < kTileProducers) tile_producer_loop<KP, NBUF, BUF, CH>(a, ring, wring, dring, c0, nch, lane, wave, tile);
+    tile_epilogue<LDO, false>(a, out_lds, tile, tid, kTileThreads);
 }
 
 // dz = da * act'(a) for an activation fused into rgcn_fwd's store (a = act(z)): relu -> (a > 0), sigmoid -> a (1 - a).
@@ -2365,7 +2412,8 @@ static int launch_tile_nbuf(const TileArgs& a, int n_tiles, size_t lds, hipStrea
                              : allow_full_lds<rgcn_tile_kernel<KP, NP, NBUF, false, CH>>();
     if (e != hipSuccess) return (int)e;
     auto kern = a.x_bytes ? rgcn_tile_kernel<KP, NP, NBUF, true, CH> : rgcn_tile_kernel<KP, NP, NBUF, false, CH>;
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(kTileThreads), lds, stream, a);
+    const int nwg = (n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(kTileThreads), lds, stream, a);
     return (int)hipGetLastError();
 }
 // deepest DMA ring (4, 3 or 2 slots) that fits beside the tile accumulator in the 160 KiB LDS
@@ -2448,6 +2496,9 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.mask = mask;
     a.ldm = ldm;
     a.act = act;
+    a.n_tiles = plan->n_tiles;
+    // tiles per workgroup: up to 16 while at least 512 workgroups (two rounds of the 256 CUs) remain for balance
+    a.tiles_per_wg = plan->n_tiles / 512 < 1 ? 1 : (plan->n_tiles / 512 > 16 ? 16 : plan->n_tiles / 512);
 #ifdef RGCN_DEBUG_KNOBS
     a.dbg = g_debug_mode.load();
 #else
@@ -2459,6 +2510,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
         const size_t lds = sizeof(float) * ((size_t)(a.tile + 1) * kAccStride<64> + (size_t)2 * 128 * (64 + 2));
         if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
         a.wp = packed + (size_t)(plan->num_relations + 1) * KP * NP;
+        a.tiles_per_wg = 1;
         hipError_t e = a.x_bytes ? allow_full_lds<rgcn_tile3_kernel<true>>() : allow_full_lds<rgcn_tile3_kernel<false>>();
         if (e != hipSuccess) return (int)e;
         auto kern = a.x_bytes ? rgcn_tile3_kernel<true> : rgcn_tile3_kernel<false>;
