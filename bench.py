@@ -124,7 +124,7 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5):
+def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5, graph=False):
     """fwd + bwd of one layer through the drop-in module on a fresh synthetic graph: (median ms per step, plan s)"""
     from scaling_rgcn_training_amd.conv import RGCNConv
     from scaling_rgcn_training_amd.plan import clear_plan_cache
@@ -151,8 +151,28 @@ def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5):
             evs.append((a, b))
     torch.cuda.synchronize()
     ms = statistics.median(a.elapsed_time(b) for a, b in evs)
+    ms_graph = None
+    if graph:
+        # the same step captured once in a hipGraph and replayed: what a launch-bound small graph costs without the
+        # host between its ~12 launches (the library never synchronises or allocates on the layer path, so capture works)
+        x.grad = None
+        conv.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            conv(x, ei, et).backward(dg)
+        evs = []
+        for i in range(warmup + steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            b.record()
+            if i >= warmup:
+                evs.append((a, b))
+        torch.cuda.synchronize()
+        ms_graph = statistics.median(a.elapsed_time(b) for a, b in evs)
+        del g
     clear_plan_cache()
-    return ms, plan_s
+    return ms, plan_s, ms_graph
 
 
 def main():
@@ -294,9 +314,16 @@ def main():
         for ps, p in psb:
             _lib.bwd_dx(ps, dg, d, pkt, dxb[:p.n_owned], d, None, kf)
 
-    def run_dw():
+    dwp = getattr(plans, "dw", None) if world == 1 else None
+    psd = _lib.plan_struct(dwp) if dwp is not None else None
+
+    def run_dw():      # what the module's backward launches (conv.py): tile-major kernel + root part, or the relation-major walk
+        if psd is not None:
+            _lib.bwd_dw_tiles(psd, plans.dw_walk, xd, d, dg, d, dw, kf)
+            _lib.bwd_dw(psf[0][0], xd, d, dg, d, None, dr, db, kf | _lib.FLAG_DW_ROOT_ONLY)
+            return
         for ps, p in psf:
-            _lib.bwd_dw(ps, xd, d, dg[p.node_begin:p.node_end], d, dw, dr, db)
+            _lib.bwd_dw(ps, xd, d, dg[p.node_begin:p.node_end], d, dw, dr, db, kf)
 
     launches = {"fwd": run_fwd, "dx": run_dx, "dw": run_dw}
     kernel_ms = {}
@@ -312,7 +339,8 @@ def main():
         torch.cuda.synchronize()
         kernel_ms[name] = statistics.median(a.elapsed_time(b) for a, b in kevs)
         log(f"launch {name}: {kernel_ms[name]:.3f} ms (median of {reps})")
-    # the forward and dX launches run the same kernel (rgcn_tile_kernel); dw = memsets + rgcn_dw_direct_kernel + reduce
+    # the forward and dX launches run the same kernel (rgcn_tile_kernel); dw = rgcn_dw_tile_kernel + reduce + the root part
+    # (rgcn_dw_direct_kernel on the root units), or memsets + rgcn_dw_direct_kernel + reduce without a dW plan
     alg = algorithmic_bytes(e / world, n / world, r, d, d)
     flops = algorithmic_flops(e / world, n / world, r, d, d)
     tile_ms = kernel_ms["fwd"] + kernel_ms["dx"]
@@ -320,7 +348,7 @@ def main():
         kname, prof_name = "rgcn_tile_kernel (fwd + dX launches)", "rgcn::rgcn_tile_kernel<64, 64"
         kbytes, kflops, kms = (alg["fwd"] + alg["dx"]) / 2, (flops["fwd"] + flops["dx"]) / 2, tile_ms / 2
     else:
-        kname, prof_name = "rgcn_dw_direct_kernel (dW launch)", "rgcn::rgcn_dw_direct_kernel"
+        kname, prof_name = "dW launches", "rgcn::rgcn_dw_tile_kernel" if psd is not None else "rgcn::rgcn_dw_direct_kernel"
         kbytes, kflops, kms = alg["dw"], flops["dw"], kernel_ms["dw"]
     hbm_achieved = kbytes / (kms * 1e-3) / 1e9
     mfma_achieved = kflops / (kms * 1e-3) / 1e12
@@ -384,17 +412,20 @@ def main():
     # ---- the smaller rungs and the CPU baseline beside its rung (N = 1 only) ----------------------------------------
     if world == 1 and rank == 0:
         from scaling_rgcn_training_amd.plan import clear_plan_cache
-        del plans, psf, psb, fps, bps, out, dxb, x, xd, dg, ei, et, conv, _pl
+        del plans, psf, psb, psd, dwp, fps, bps, out, dxb, x, xd, dg, ei, et, conv, _pl
         clear_plan_cache()
         torch.cuda.empty_cache()
         if not args.no_ladder:
             ladder = [{"rung": "10M/100M", "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
                        "gpu_ms_per_step": rec["ms_per_step_median"], "gpu_edges_per_s": e / (rec["ms_per_step_median"] * 1e-3)}]
             for name, ln, le, lr, lin, lout in LADDER:
-                ms, ps_ = gpu_rung(ln, le, lr, lin, lout, dev)
+                ms, ps_, msg = gpu_rung(ln, le, lr, lin, lout, dev, graph=le <= 1_000_000)
                 ladder.append({"rung": name, "nodes": ln, "edges": le, "relations": lr, "in": lin, "out": lout,
                                "gpu_ms_per_step": ms, "gpu_edges_per_s": le / (ms * 1e-3), "plan_build_s": ps_})
-                log(f"ladder {name}: {ms:.3f} ms/step = {le / (ms * 1e-3):.3e} edges/s")
+                if msg is not None:
+                    ladder[-1]["gpu_ms_per_step_hipgraph_replay"] = msg
+                log(f"ladder {name}: {ms:.3f} ms/step = {le / (ms * 1e-3):.3e} edges/s" +
+                    (f" (captured in a hipGraph: {msg:.3f} ms/step)" if msg is not None else ""))
             rec["ladder"] = ladder
         if not args.no_cpu_baseline:
             log(f"timing the CPU baseline on the {CPU_RUNG[0]} rung (one pass, {host_threads()} threads)")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 10
+#define RGCN_ABI_VERSION 11
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -202,9 +202,11 @@ int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const
  * once per relation quarter instead of being gathered per edge (37 GB instead of 55 GB moved at the headline config).
  * `plan`: a FORWARD-direction plan built with the geometry rgcn_dw_tiles_geometry reports (tile = 304, chunk = 64, layout
  * 0); walk_ptr: int32 [num_relations][walkers + 1], walk_ptr[r][p] = first position in plan->rel_order of relation r
- * whose tile is >= p * n_tiles / walkers (integer division), walk_ptr[r][walkers] = end of relation r.
+ * whose tile is >= p * n_tiles / walkers (integer division), walk_ptr[r][walkers] = end of relation r; filled by
+ * rgcn_dw_tiles_walk (once per plan; walk_ptr: device memory, num_relations * (walkers + 1) int32).
  * d_root / d_bias: rgcn_bwd_dw(..., RGCN_FLAG_DW_ROOT_ONLY) on any forward plan of the same graph. */
 int rgcn_dw_tiles_geometry(int* tile, int* walkers, int* max_relations);
+int rgcn_dw_tiles_walk(const rgcn_plan_t* plan, int32_t* walk_ptr, void* stream);
 size_t rgcn_bwd_dw_tiles_workspace_bytes(int num_relations);
 int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_ptr, const float* x, int ldx, int din, const float* g,
                       int ldg, int dout, void* workspace, size_t workspace_bytes, float* d_weight, unsigned flags,

@@ -14,13 +14,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
     "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_act_backward", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
     "rgcn_plan_workspace_bytes", "rgcn_edge_weights", "rgcn_plan_build_begin", "rgcn_plan_build_finish",
-    "rgcn_dw_tiles_geometry", "rgcn_bwd_dw_tiles_workspace_bytes", "rgcn_bwd_dw_tiles",
+    "rgcn_dw_tiles_geometry", "rgcn_dw_tiles_walk", "rgcn_bwd_dw_tiles_workspace_bytes", "rgcn_bwd_dw_tiles",
 )
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
@@ -104,6 +104,8 @@ def load() -> C.CDLL:
     lib.rgcn_plan_build_finish.argtypes = [C.POINTER(RgcnPlanSizes), vp, sz, C.POINTER(RgcnPlanStruct), vp]
     lib.rgcn_dw_tiles_geometry.restype = i32
     lib.rgcn_dw_tiles_geometry.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.rgcn_dw_tiles_walk.restype = i32
+    lib.rgcn_dw_tiles_walk.argtypes = [C.POINTER(RgcnPlanStruct), vp, vp]
     lib.rgcn_bwd_dw_tiles_workspace_bytes.restype = sz
     lib.rgcn_bwd_dw_tiles_workspace_bytes.argtypes = [i32]
     lib.rgcn_bwd_dw_tiles.restype = i32
@@ -264,6 +266,15 @@ def dw_tiles_geometry():
     t, w, r = C.c_int(), C.c_int(), C.c_int()
     check(load().rgcn_dw_tiles_geometry(C.byref(t), C.byref(w), C.byref(r)), "rgcn_dw_tiles_geometry")
     return t.value, w.value, r.value
+
+
+def dw_tiles_walk(ps: RgcnPlanStruct, device) -> torch.Tensor:
+    """walk_ptr of rgcn_bwd_dw_tiles for a plan of the tile-major geometry: int32 [num_relations, walkers + 1]"""
+    walkers = dw_tiles_geometry()[1]
+    out = torch.empty(int(ps.num_relations), walkers + 1, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        check(load().rgcn_dw_tiles_walk(C.byref(ps), out.data_ptr(), _stream(out)), "rgcn_dw_tiles_walk")
+    return out
 
 
 def bwd_dw_tiles(ps: RgcnPlanStruct, walk_ptr: torch.Tensor, x: torch.Tensor, din: int, g: torch.Tensor, dout: int,

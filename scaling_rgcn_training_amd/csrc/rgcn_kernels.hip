@@ -2270,6 +2270,24 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     }
 }
 
+// walk_ptr[r][p] = first position in rel_order (sorted by (relation, tile)) of a unit of relation r whose tile is
+// >= p * n_tiles / walkers; one thread per entry, binary search (integer work, once per plan)
+__global__ void rgcn_dw_walk_table_kernel(const int* __restrict__ rel_order, const int* __restrict__ chunk_rel,
+                                          const int* __restrict__ chunk_tile, int n_units, int n_tiles, int num_rel, int walkers,
+                                          int* __restrict__ walk_ptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_rel * (walkers + 1)) return;
+    const int r = i / (walkers + 1), p = i - r * (walkers + 1);
+    const long target = (long)r * n_tiles + (long)p * n_tiles / walkers;
+    int lo = 0, hi = n_units;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = rel_order[mid];                        // 64-slot chunks: unit == chunk
+        if ((long)chunk_rel[c] * n_tiles + chunk_tile[c] < target) lo = mid + 1; else hi = mid;
+    }
+    walk_ptr[i] = lo;
+}
+
 // d_weight[r] = sum over the walkers' slabs, in walker order (bitwise reproducible)
 __global__ void rgcn_dw_tile_reduce_kernel(const float* __restrict__ slabs, int walkers, int num_rel, int din, int dout,
                                            float* __restrict__ d_weight) {
@@ -2346,6 +2364,27 @@ template <int KP>
 constexpr int tile_nbuf() { return KP == 128 ? 2 : 4; }
 template <int KP, int NP>
 constexpr int dw_nbuf() { return (KP == 128 || NP == 128) ? 2 : 4; }
+
+// Tiles one workgroup of rgcn_tile_kernel walks (1..16).  One workgroup fits a CU, so a launch runs in rounds of 256
+// workgroups, and the round count is what the time follows (tools/debug/tpw_sweep.py, forward launch, 28,410 tiles: 16
+// tiles -> 1,776 workgroups = 7 rounds x 16 = 112 tile times, 10.36 ms; 12 -> 2,368 = 10 rounds x 12 = 120, 11.48 ms;
+// 1 -> 111 rounds, 10.67 ms: a workgroup's start-up costs ~3-4 % of a tile.  2,841 tiles: 12 -> 1 round, 1.11 ms; 8 ->
+// 2 rounds x 8, 1.46 ms).  Pick the count with the least rounds x (tiles + start-up), the larger one on ties.
+static int tiles_per_workgroup(int n_tiles) {
+    constexpr int kCUs = 256;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int t = 1; t <= 16; ++t) {
+        const int wgs = (n_tiles + t - 1) / t;
+        const int rounds = (wgs + kCUs - 1) / kCUs;
+        const double cost = rounds * (t + 0.04);
+        if (cost <= best_cost * 1.002) {
+            best_cost = cost < best_cost ? cost : best_cost;
+            best = t;
+        }
+    }
+    return best;
+}
 
 static int check_plan(const rgcn_plan_t* p) {
     if (p == nullptr) return RGCN_ERR_NULL;
@@ -2497,8 +2536,10 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.ldm = ldm;
     a.act = act;
     a.n_tiles = plan->n_tiles;
-    // tiles per workgroup: up to 16 while at least 512 workgroups (two rounds of the 256 CUs) remain for balance
-    a.tiles_per_wg = plan->n_tiles / 512 < 1 ? 1 : (plan->n_tiles / 512 > 16 ? 16 : plan->n_tiles / 512);
+    a.tiles_per_wg = tiles_per_workgroup(plan->n_tiles);
+#ifdef RGCN_TPW_ENV        // experiment build only (tools/debug/tpw_sweep.py)
+    if (const char* e = getenv("RGCN_TPW")) a.tiles_per_wg = atoi(e) > 0 ? atoi(e) : a.tiles_per_wg;
+#endif
 #ifdef RGCN_DEBUG_KNOBS
     a.dbg = g_debug_mode.load();
 #else
@@ -2751,6 +2792,18 @@ extern "C" int rgcn_dw_tiles_geometry(int* tile, int* walkers, int* max_relation
     if (walkers) *walkers = kDwTileWalkers;
     if (max_relations) *max_relations = kDwTileMaxRel;
     return RGCN_OK;
+}
+
+extern "C" int rgcn_dw_tiles_walk(const rgcn_plan_t* plan, int32_t* walk_ptr, void* stream) {
+    int st;
+    if ((st = check_device()) != RGCN_OK) return st;
+    if ((st = check_plan(plan)) != RGCN_OK) return st;
+    if (walk_ptr == nullptr) return RGCN_ERR_NULL;
+    if (plan->tile != kDwTileT || plan->chunk != 64 || plan->layout != 0 || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
+    const int n = plan->num_relations * (kDwTileWalkers + 1);
+    hipLaunchKernelGGL(rgcn_dw_walk_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan->rel_order,
+                       plan->chunk_rel, plan->chunk_tile, plan->n_units, plan->n_tiles, plan->num_relations, kDwTileWalkers, walk_ptr);
+    return (int)hipGetLastError();
 }
 
 extern "C" size_t rgcn_bwd_dw_tiles_workspace_bytes(int num_relations) {

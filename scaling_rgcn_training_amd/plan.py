@@ -470,14 +470,14 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
             t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
             if num_relations <= max_rel:
                 gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, 0, n_nodes, ws, False)
-                gp.dw_walk = dw_walk_table(gp.dw, walkers)
+                gp.dw_walk = _lib.dw_tiles_walk(_lib.plan_struct(gp.dw), edge_type.device)
         out.append(gp)
     del keep
     return out if ranges is not None else out[0]
 
 
 def dw_walk_table(plan: TilePlan, walkers: int) -> Tensor:
-    """walk_ptr of rgcn_bwd_dw_tiles: for relation r and walker p the first position in ``plan.rel_order`` (sorted by
+    """Torch form (test oracle) of rgcn_dw_tiles_walk -- walk_ptr of rgcn_bwd_dw_tiles: for relation r and walker p the first position in ``plan.rel_order`` (sorted by
     (relation, tile)) of a unit of relation r whose tile is >= p * n_tiles // walkers; column ``walkers`` = end of relation r."""
     dev = plan.rel_order.device
     units = plan.rel_order.long()

@@ -421,6 +421,8 @@ def test_dw_tile_major_kernel(dev, n, e, r, skew):
     assert r <= max_rel
     plans = P.build_graph_plans_device(ei.to(dev), et.to(dev), n, r, 128, dw_tiles=True)
     assert plans.dw is not None and plans.dw.tile == t_dw and plans.dw.chunk == 64 and plans.dw_walk.shape == (r, walkers + 1)
+    # rgcn_dw_tiles_walk (integer work: bit-exact) against its torch form
+    assert torch.equal(plans.dw_walk, P.dw_walk_table(plans.dw, walkers))
     xd, gd = x.to(dev), dg.to(dev)
     dw = torch.full((r, din, dout), float("nan"), device=dev)
     _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, xd, din, gd, dout, dw)
