@@ -873,6 +873,10 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
                 tile_epilogue<LDO, true>(a, out_lds, tile_cur, tid - 64 * kTileProducers, kTileThreads - 64 * kTileProducers);
                 ++tile_cur;
                 tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
+                // retire the epilogue's loads and stores in the compiler's scoreboard HERE (once per tile): left pending
+                // across the back edge they put an s_waitcnt vmcnt(0) at the top of EVERY iteration (first reuse of a
+                // register the mask loads had written), which also waits for the B prefetch issued a moment earlier
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 wg_barrier();
             }
             STAMP_ADD(st_scal, t0, t1);
