@@ -340,8 +340,8 @@ def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: i
     sqrt(g)) takes E[ceil(g / chunk)] chunks and ~g / 16 + 1/2 row tiles, so larger tiles and 128-slot chunks
     amortise the fixed part -- within the LDS: (tile + 1) * (pad(width) + 4) * 4 B of accumulator plus at least two
     ring slots of chunk * (pad(other width) + 2) * 4 B (three cost nothing extra; with two the producers run only one
-    chunk ahead: +3 %).  128-slot chunks are built for widths <= 64.  Small graphs keep >= 512 tiles (two workgroups
-    per CU) as long as the tile does not drop below 64 nodes, whatever the model says."""
+    chunk ahead: +3 %).  128-slot chunks are built for widths <= 64.  The launch runs in rounds of 256 workgroups that
+    walk up to 16 tiles each, so what is minimised is rounds x cycles per tile."""
     import math
     kp, np_ = padded_width(in_channels), padded_width(out_channels)
     density = n_edges / max(1.0, float(n_nodes) * max(1, num_relations))
@@ -364,14 +364,18 @@ def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: i
         root = math.ceil(t / chunk) * 800.0 + (t / 16.0) * 650.0
         return ring_penalty * (max(1, num_relations) * per_rel + root) / t      # cycles per output node
 
-    cands = [(t, c) for c in CHUNKS for t in range(64, 513, 32)
+    def launch_rounds(n_tiles):
+        # tile times one launch takes: a workgroup (one per CU, 256 CUs) walks up to 16 tiles, start-up ~4 % of a tile;
+        # the library picks the count the same way (csrc/rgcn_kernels.hip tiles_per_workgroup)
+        return min(math.ceil(math.ceil(n_tiles / k) / 256) * (k + 0.04) for k in range(1, 17))
+
+    cands = [(t, c) for c in CHUNKS for t in range(64, 513, 16)
              if lds(t, c, 2) <= LDS_BYTES and (c == CHUNK or max(kp, np_) <= 64)]
     if not cands:
         return 64, CHUNK
-    few = [tc for tc in cands if n_nodes // tc[0] >= 512]
-    if not few:
-        return min(t for t, _ in cands), CHUNK
-    return min(few, key=lambda tc: (round(cost(*tc), 1), -tc[0]))
+    # time of a launch ~ rounds x (cycles per tile): on large graphs this is the cost per node, on small ones the round
+    # count decides (100k nodes: 285 tiles of 352 are two rounds with the second one a ninth full)
+    return min(cands, key=lambda tc: (round(launch_rounds(math.ceil(n_nodes / tc[0])) * cost(*tc) * tc[0] / 1e3, 1), -tc[0]))
 
 
 def run_metadata(slot_dstl: Tensor, tile: int):
