@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 11
+#define RGCN_ABI_VERSION 12
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -211,6 +211,15 @@ size_t rgcn_bwd_dw_tiles_workspace_bytes(int num_relations);
 int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_ptr, const float* x, int ldx, int din, const float* g,
                       int ldg, int dout, void* workspace, size_t workspace_bytes, float* d_weight, unsigned flags,
                       void* stream);
+
+/* d_root = x^T g and d_bias = column sums of g over rows [0, rows) of the two matrices -- the self-loop ("root") part of
+ * autograd's backward of RGCNConv (reference model/modelTrainer.py:66), which needs no plan: the rows the root relation
+ * "gathers" are the nodes' own.  Widths up to 64 per side (RGCN_ERR_WIDTH beyond: use rgcn_bwd_dw with
+ * RGCN_FLAG_DW_ROOT_ONLY).  A streaming kernel without LDS whose workgroups fit a CU next to rgcn_bwd_dx's: enqueue it on a
+ * second stream beside the dX launch.  d_root or d_bias may be NULL (not both).  Bit-reproducible. */
+size_t rgcn_bwd_dw_root_workspace_bytes(void);
+int rgcn_bwd_dw_root(const float* x, int ldx, int din, const float* g, int ldg, int dout, long rows, void* workspace,
+                     size_t workspace_bytes, float* d_root, float* d_bias, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,13 +14,14 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
     "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_act_backward", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
     "rgcn_plan_workspace_bytes", "rgcn_edge_weights", "rgcn_plan_build_begin", "rgcn_plan_build_finish",
     "rgcn_dw_tiles_geometry", "rgcn_dw_tiles_walk", "rgcn_bwd_dw_tiles_workspace_bytes", "rgcn_bwd_dw_tiles",
+    "rgcn_bwd_dw_root_workspace_bytes", "rgcn_bwd_dw_root",
 )
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
@@ -110,6 +111,10 @@ def load() -> C.CDLL:
     lib.rgcn_bwd_dw_tiles_workspace_bytes.argtypes = [i32]
     lib.rgcn_bwd_dw_tiles.restype = i32
     lib.rgcn_bwd_dw_tiles.argtypes = [C.POINTER(RgcnPlanStruct), vp, vp, i32, i32, vp, i32, i32, vp, sz, vp, u32, vp]
+    lib.rgcn_bwd_dw_root_workspace_bytes.restype = sz
+    lib.rgcn_bwd_dw_root_workspace_bytes.argtypes = []
+    lib.rgcn_bwd_dw_root.restype = i32
+    lib.rgcn_bwd_dw_root.argtypes = [vp, i32, i32, vp, i32, i32, C.c_long, vp, sz, vp, vp, vp]
     if lib.rgcn_abi_version() != ABI_VERSION:
         raise RgcnLibraryError(f"ABI version mismatch: library {lib.rgcn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
@@ -285,3 +290,15 @@ def bwd_dw_tiles(ps: RgcnPlanStruct, walk_ptr: torch.Tensor, x: torch.Tensor, di
     with torch.cuda.device(x.device):
         check(lib.rgcn_bwd_dw_tiles(C.byref(ps), walk_ptr.data_ptr(), x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0),
                                     dout, ws.data_ptr(), nbytes, d_weight.data_ptr(), int(flags), _stream(x)), "rgcn_bwd_dw_tiles")
+
+
+def bwd_dw_root(x: torch.Tensor, din: int, g: torch.Tensor, dout: int, d_root: Optional[torch.Tensor],
+                d_bias: Optional[torch.Tensor]) -> None:
+    """d_root = x^T g, d_bias = column sums of g (rgcn_bwd_dw_root): rows of x and g pair up one to one."""
+    lib = load()
+    if x.shape[0] != g.shape[0]:
+        raise RgcnLibraryError("rgcn_bwd_dw_root: x and g must have the same number of rows")
+    with torch.cuda.device(x.device):
+        ws = torch.empty(lib.rgcn_bwd_dw_root_workspace_bytes(), dtype=torch.uint8, device=x.device)
+        check(lib.rgcn_bwd_dw_root(x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0), dout, x.shape[0],
+                                   ws.data_ptr(), ws.numel(), _ptr(d_root), _ptr(d_bias), _stream(x)), "rgcn_bwd_dw_root")

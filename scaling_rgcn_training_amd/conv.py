@@ -43,6 +43,18 @@ _SPLIT_PRECISION_DEFAULT = os.environ.get("RGCN_SPLIT_PRECISION", "0") == "1"
 DW_TILES_MIN_EDGES = 4_000_000
 
 _ACT_CODES = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID}
+# graphs from this many nodes run the root / bias gradient kernel on a side stream beside the dX launch (below it the step is
+# launch-bound and a second stream only adds event traffic)
+_SIDE_STREAM_MIN_ROWS = int(os.environ.get("RGCN_SIDE_STREAM_MIN_ROWS", 262144))
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def layout_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0,
@@ -185,48 +197,66 @@ class _RGCNLayerFn(torch.autograd.Function):
         if ctx.need_a:
             gp = _lib.act_backward(a_out, gp, ctx.act)       # dL/dz = dL/da * act'(a)
         dx = dw = droot = dbias = None
+        need_root = need_root and ctx.has_root
+        need_bias = need_bias and ctx.has_bias
+        dev = g.device
+        # ONE flat buffer for the three weight gradients (a single all-reduce in the distributed case)
+        sizes = [num_rel * din * dout if need_w else 0, din * dout if need_root else 0, dout if need_bias else 0]
+
+        def views(flat):
+            o0, o1 = sizes[0], sizes[0] + sizes[1]
+            return (flat[:o0].view(num_rel, din, dout) if need_w else None,
+                    flat[o0:o1].view(din, dout) if need_root else None,
+                    flat[o1:].view(dout) if need_bias else None)
+
+        # Single-GPU layers whose d_weight goes to the tile-major kernel: d_root / d_bias come from the plan-free streaming
+        # kernel (rgcn_bwd_dw_root).  On large graphs it is enqueued on a SIDE stream before the dX launch: it is HBM-bound
+        # with a tenth of a launch's MFMAs, uses no LDS and few registers, so its workgroups share the CUs with the MFMA-bound
+        # dX kernel instead of adding their ~1 ms behind it.  The join is a stream wait, never a host sync.
+        dwp = getattr(plans, "dw", None) if dctx is None else None
+        tiles_path = (dwp is not None and need_w and plans.fwd.n_owned > 0 and
+                      not (flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)))
+        tiles_part = side = None
+        if tiles_path:
+            tiles_part = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            _, pr, pb = views(tiles_part)
+            if need_root or need_bias:
+                if need_x and n >= _SIDE_STREAM_MIN_ROWS:
+                    side = _side_stream(dev)
+                    side.wait_stream(torch.cuda.current_stream(dev))      # gp (and xp) are produced on the current stream
+                    with torch.cuda.stream(side):
+                        _lib.bwd_dw_root(xp, din, gp, dout, pr, pb)
+                else:
+                    _lib.bwd_dw_root(xp, din, gp, dout, pr, pb)
         if need_x:
             packed_t = _lib.pack_weights(wf, rt, transpose=True)
             ldx = _round4(din)
             mask = xp if ctx.input_relu else None            # x = relu(z_prev): store dL/dz_prev = dx * (x > 0)
             if dctx is None:
-                dxp = torch.empty(n, ldx, dtype=torch.float32, device=g.device)
+                dxp = torch.empty(n, ldx, dtype=torch.float32, device=dev)
                 _lib.bwd_dx(_lib.plan_struct(plans.bwd), gp, dout, packed_t, dxp, din, mask, flags)
             else:
                 dxp = _gather_pieces(
                     dctx, [p.bwd for p in plans.pieces],
                     lambda pl, rows: _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din,
                                                  None if mask is None else mask[pl.node_begin:pl.node_end], flags),
-                    ldx, n, g.device)
+                    ldx, n, dev)
             dx = dxp if ldx == din else dxp[:, :din]
-        need_root = need_root and ctx.has_root
-        need_bias = need_bias and ctx.has_bias
-        if need_w or need_root or need_bias:
-            dev = g.device
+        if tiles_path:
+            # relations: tile-major kernel (gradient rows staged in LDS)
+            _lib.bwd_dw_tiles(_lib.plan_struct(dwp), plans.dw_walk, xp, din, gp, dout, views(tiles_part)[0], flags)
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+            dw, droot, dbias = views(tiles_part)
+        elif need_w or need_root or need_bias:
             fplans = [plans.fwd] if dctx is None else [p.fwd for p in plans.pieces]
-            sizes = [num_rel * din * dout if need_w else 0, din * dout if need_root else 0, dout if need_bias else 0]
-
-            def views(flat):
-                o0, o1 = sizes[0], sizes[0] + sizes[1]
-                return (flat[:o0].view(num_rel, din, dout) if need_w else None,
-                        flat[o0:o1].view(din, dout) if need_root else None,
-                        flat[o1:].view(dout) if need_bias else None)
-
-            # ONE flat buffer for the three gradients: a single all-reduce in the distributed case
             acc = None
-            dwp = getattr(plans, "dw", None) if dctx is None else None
             for fp in fplans:
                 if fp.n_owned <= 0:
                     continue
                 part = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
                 pw, pr, pb = views(part)
-                if dwp is not None and need_w and not (flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)):
-                    # relations: tile-major kernel (gradient rows staged in LDS); root + bias: relation-major walk of the root units
-                    _lib.bwd_dw_tiles(_lib.plan_struct(dwp), plans.dw_walk, xp, din, gp, dout, pw, flags)
-                    if need_root or need_bias:
-                        _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp, dout, None, pr, pb, flags | _lib.FLAG_DW_ROOT_ONLY)
-                else:
-                    _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb, flags)
+                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb, flags)
                 acc = part if acc is None else acc.add_(part)
             if acc is None:
                 acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)

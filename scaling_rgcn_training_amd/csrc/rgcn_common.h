@@ -11,6 +11,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <cstring>
+#include "../../include/rgcn_mi355x.h"
 
 namespace rgcn {
 
@@ -115,5 +118,29 @@ __host__ __device__ inline int padded_width(int w) {
     if (w < 1 || w > 128) return 0;
     return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 64 : 128));
 }
+
+
+// ---- host-side argument checks shared by the translation units of the library ----------------------------------
+// The library is gfx950 code only: any other device (or none) is RGCN_ERR_DEVICE.  Looked up once per device.
+inline int check_device() {
+    static std::atomic<int> state[64];          // 0 unknown, 1 gfx950, 2 other
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return RGCN_ERR_DEVICE;
+    if (dev >= 64) return RGCN_ERR_DEVICE;
+    int st = state[dev].load(std::memory_order_relaxed);
+    if (st == 0) {
+        hipDeviceProp_t prop;
+        st = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 2;
+        state[dev].store(st, std::memory_order_relaxed);
+    }
+    return st == 1 ? RGCN_OK : RGCN_ERR_DEVICE;
+}
+
+inline int check_stride(int ld, int width) {
+    if (width < 1 || width > RGCN_MAX_WIDTH) return RGCN_ERR_WIDTH;
+    if ((ld % 4) != 0 || ld < ((width + 3) / 4) * 4) return RGCN_ERR_STRIDE;
+    return RGCN_OK;
+}
+
 
 }  // namespace rgcn

@@ -43,6 +43,15 @@ __device__ __forceinline__ unsigned long long stamp() {
 #ifndef RGCN_PRIO
 #define RGCN_PRIO 3
 #endif
+// 1: the Y^T path's 16 MFMAs of a row tile form ONE dependent chain (back-to-back dependent v_mfma_f32_16x16x4_f32 issue at
+// full rate on gfx950), so the accumulate is 2 packed FMAs per tile; 0: two chains folded by 6 FMAs (measured 0.9 % slower)
+#ifndef RGCN_ONE_CHAIN
+#define RGCN_ONE_CHAIN 1
+#endif
+// tile-major dW: cut a unit's tail at the 4-row k-step instead of the 16-row group
+#ifndef RGCN_DW_KSTEP_GATE
+#define RGCN_DW_KSTEP_GATE 0
+#endif
 // cache policy of the direct dW kernel's x-row gathers (aux bits of buffer_load): 0 default, 2 = nt (streamed once)
 #ifndef RGCN_DW_X_AUX
 #define RGCN_DW_X_AUX 0
@@ -671,14 +680,23 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
                             continue;
                         }
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][i], o.av[j][i], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][i + 1], o.av[j][i + 1], acc1, 0, 0, 0);
+                        if (RGCN_ONE_CHAIN)
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][i + 1], o.av[j][i + 1], acc0, 0, 0, 0);
+                        else
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[s][j][i + 1], o.av[j][i + 1], acc1, 0, 0, 0);
                     }
                     t.y[s] = acc0;      // the two chains are folded in stage C's FMAs
                     t.z[s] = acc1;
                 }
             };
             auto stage_b_t = [&](const Ops& o, Tile& t) {     // old accumulator contents (after tile t-1's store)
+#if RGCN_ABL & 8
+                // timing-only diagnostic (WRONG results): the 16 lanes of a ds_read_b128 phase address rows that differ
+                // mod 16 -- what a conflict-free accumulator layout could buy
+                t.dst[0] = acc_ptr((o.d1 & 0xFFFFF0) | rowl, lane_col4_bytes);
+#else
                 t.dst[0] = acc_ptr(o.d1, lane_col4_bytes);
+#endif
 #pragma unroll
                 for (int s = 0; s < SL; ++s) t.old[s] = *(const f32x4*)(t.dst[0] + 16 * CW * s);
             };
@@ -686,7 +704,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
 #pragma unroll
                 for (int s = 0; s < SL; ++s) {
                     f32x4 v = t.y[s] * o.w1 + t.old[s];
-                    v = t.z[s] * o.w1 + v;
+                    if (!RGCN_ONE_CHAIN) v = t.z[s] * o.w1 + v;
                     *(f32x4*)(t.dst[0] + 16 * CW * s) = v;
                 }
             };
@@ -2192,7 +2210,7 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     };
     // half a unit: 8 k-steps of 4 rows; gradient rows from the LDS tile (row ids local to the tile, padding clamped: its
     // weight is 0 and every LDS word is a finite number)
-    auto compute_half = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {
+    auto compute_half = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, int nks, const float* gbuf, int tile_row0) {
         const unsigned loc = (unsigned)(ix.g - tile_row0);
         const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));    // byte offset of this lane's slot row
         float wv[HS];
@@ -2209,6 +2227,9 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int s = 4 * gi + t;
+                    // (cutting a unit's tail at the 4-row k-step instead of the 16-row group -- ~6 % fewer MFMAs -- measured
+                    // 1 % SLOWER: 8.25 against 8.16 ms; the walk is not bound by its MFMA count.  Knob: RGCN_DW_KSTEP_GATE)
+                    if (RGCN_DW_KSTEP_GATE && HS * h + s >= nks) break;
                     f32x4 bv = g4[s] * wv[s];
                     asm volatile("s_nop 4" : "+v"(bv));       // VALU write -> asm MFMA operand (see rgcn_dw_direct_kernel)
 #pragma unroll
@@ -2238,15 +2259,15 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
         if (t + 1 < t1) dma_tile(t + 1, b ^ 1);
         const float* gbuf = lds + b * T * NP;
         while (k < nun && tile_cur == t) {
-            const int ngrp = (cnt_cur + 15) >> 4;
+            const int ngrp = (cnt_cur + 15) >> 4, nks = (cnt_cur + 3) >> 2;
             issue_half(s1, ix_cur, 1);
             __builtin_amdgcn_sched_barrier(0);
-            compute_half(s0, ix_cur, 0, ngrp, gbuf, t * T);
+            compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             const Idx ix_nn = load_idx(uid_nn);
             issue_half(s0, ix_nxt, 0);
             __builtin_amdgcn_sched_barrier(0);
-            compute_half(s1, ix_cur, 1, ngrp, gbuf, t * T);
+            compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             ++k;
             ix_cur = ix_nxt;
@@ -2414,21 +2435,6 @@ static unsigned buffer_bytes(int rows, int ld, unsigned flags) {
     return (rows < (1 << 24) && with_pad_row < 0xFFFFFF00ull) ? (unsigned)bytes : 0u;
 }
 
-// The library is gfx950 code only: any other device (or none) is RGCN_ERR_DEVICE.  Looked up once per device.
-static int check_device() {
-    static std::atomic<int> state[64];          // 0 unknown, 1 gfx950, 2 other
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return RGCN_ERR_DEVICE;
-    if (dev >= 64) return RGCN_ERR_DEVICE;
-    int st = state[dev].load(std::memory_order_relaxed);
-    if (st == 0) {
-        hipDeviceProp_t prop;
-        st = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 2;
-        state[dev].store(st, std::memory_order_relaxed);
-    }
-    return st == 1 ? RGCN_OK : RGCN_ERR_DEVICE;
-}
-
 // Opt a kernel instantiation into the full 160 KiB of dynamic LDS: once per (instantiation, device), not per launch.
 template <auto KERN>
 static hipError_t allow_full_lds() {
@@ -2441,12 +2447,6 @@ static hipError_t allow_full_lds() {
     e = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
     return e;
-}
-
-static int check_stride(int ld, int width) {
-    if (width < 1 || width > RGCN_MAX_WIDTH) return RGCN_ERR_WIDTH;
-    if ((ld % 4) != 0 || ld < ((width + 3) / 4) * 4) return RGCN_ERR_STRIDE;
-    return RGCN_OK;
 }
 
 template <int KP, int NP, int NBUF, int CH>

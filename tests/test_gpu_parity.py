@@ -443,3 +443,31 @@ def test_dw_tile_major_kernel(dev, n, e, r, skew):
     assert_close(db.cpu().numpy(), db0.cpu().numpy(), c["bias"], "root-only vs full walk d_bias")
     if r > 2:
         assert torch.all(dw[r - 1] == 0)
+
+
+@pytest.mark.parametrize("rows,din,dout", [(1, 64, 64), (3, 5, 7), (50, 63, 16), (4097, 64, 64), (20011, 16, 33),
+                                           (300000, 64, 64)])
+def test_dw_root_streaming_kernel(dev, rows, din, dout):
+    """rgcn_bwd_dw_root (plan-free d_root = x^T g, d_bias = column sums of g; widths up to 64, any row count, padded row
+    strides) against float64 and against the fp32 CPU matmul's own error; bit-reproducible; both outputs optional."""
+    from scaling_rgcn_training_amd import _lib
+    g = torch.Generator().manual_seed(rows + din)
+    ldx, ldg = (din + 3) // 4 * 4, (dout + 3) // 4 * 4
+    x = torch.zeros(rows, ldx)
+    x[:, :din] = torch.randn(rows, din, generator=g)
+    dg = torch.zeros(rows, ldg)
+    dg[:, :dout] = torch.randn(rows, dout, generator=g)
+    xd, gd = x.to(dev), dg.to(dev)
+    dr, db = torch.full((din, dout), 7.0, device=dev), torch.full((dout,), 7.0, device=dev)
+    _lib.bwd_dw_root(xd, din, gd, dout, dr, db)
+    x64, g64 = x[:, :din].double().numpy(), dg[:, :dout].double().numpy()
+    ref_r, ref_b = x64.T @ g64, g64.sum(0)
+    cond_r, cond_b = np.abs(x64).T @ np.abs(g64), np.abs(g64).sum(0)
+    cpu_r = (x[:, :din].t() @ dg[:, :dout]).numpy()
+    cpu_b = dg[:, :dout].sum(0).numpy()
+    assert_close(dr.cpu().numpy(), ref_r, cond_r, f"d_root (streaming kernel) [{rows}x{din}x{dout}]", cpu32=cpu_r, cpu_factor=4.0)
+    assert_close(db.cpu().numpy(), ref_b, cond_b, f"d_bias (streaming kernel) [{rows}x{din}x{dout}]", cpu32=cpu_b, cpu_factor=4.0)
+    dr2, db2 = torch.empty_like(dr), torch.empty_like(db)
+    _lib.bwd_dw_root(xd, din, gd, dout, dr2, None)
+    _lib.bwd_dw_root(xd, din, gd, dout, None, db2)
+    assert torch.equal(dr, dr2) and torch.equal(db, db2)
