@@ -320,7 +320,7 @@ def main():
     def run_dw():      # what the module's backward launches (conv.py): tile-major kernel + root part, or the relation-major walk
         if psd is not None:
             _lib.bwd_dw_tiles(psd, plans.dw_walk, xd, d, dg, d, dw, kf)
-            _lib.bwd_dw(psf[0][0], xd, d, dg, d, None, dr, db, kf | _lib.FLAG_DW_ROOT_ONLY)
+            _lib.bwd_dw_root(xd, d, dg, d, dr, db)       # (the module enqueues it on a side stream beside dX: conv.py)
             return
         for ps, p in psf:
             _lib.bwd_dw(ps, xd, d, dg[p.node_begin:p.node_end], d, dw, dr, db, kf)
@@ -340,7 +340,8 @@ def main():
         kernel_ms[name] = statistics.median(a.elapsed_time(b) for a, b in kevs)
         log(f"launch {name}: {kernel_ms[name]:.3f} ms (median of {reps})")
     # the forward and dX launches run the same kernel (rgcn_tile_kernel); dw = rgcn_dw_tile_kernel + reduce + the root part
-    # (rgcn_dw_direct_kernel on the root units), or memsets + rgcn_dw_direct_kernel + reduce without a dW plan
+    # (rgcn_dw_root_kernel, timed here BEHIND the tile-major kernel; in a step it runs beside dX), or memsets +
+    # rgcn_dw_direct_kernel + reduce without a dW plan
     alg = algorithmic_bytes(e / world, n / world, r, d, d)
     flops = algorithmic_flops(e / world, n / world, r, d, d)
     tile_ms = kernel_ms["fwd"] + kernel_ms["dx"]
