@@ -26,3 +26,25 @@ def cpu_twin(model):
     twin.rgcn1, twin.rgcn2 = OracleConv(model.rgcn1), OracleConv(model.rgcn2)
     twin.fuse_activations = False
     return twin
+
+
+def oracleize_(model):
+    """IN PLACE: swap the model's two RGCNConv layers for OracleConv (same parameters) and unfuse the tail, so that the
+    reference's flow -- which builds its models itself (Trainer.train_summaries / train_original) and re-binds their
+    parameters (override_params) -- can run as a CPU twin."""
+    if not isinstance(model.rgcn1, OracleConv):
+        model.rgcn1, model.rgcn2 = OracleConv(model.rgcn1), OracleConv(model.rgcn2)
+        model.fuse_activations = False
+    return model
+
+
+def make_cpu_twin_trainer(trainer_cls):
+    """A Trainer that runs the same flow on the CPU through the oracle (every model it trains is oracleize_d first)."""
+
+    class CpuTwinTrainer(trainer_cls):
+        device = torch.device("cpu")
+
+        def train(self, model, graph, loss_f, activation, sum_graph=True):
+            return super().train(oracleize_(model), graph, loss_f, activation, sum_graph)
+
+    return CpuTwinTrainer
