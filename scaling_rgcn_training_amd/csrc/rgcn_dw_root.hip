@@ -159,6 +159,9 @@ extern "C" int rgcn_bwd_dw_root(const float* x, int ldx, int din, const float* g
     const long want = (ksteps + 2 * kRootBatch - 1) / (2 * kRootBatch);      // at least one double batch per wave
     a.waves = (int)(want < 4 ? 4 : (want > kRootMaxWaves ? kRootMaxWaves : want));
     a.want_bias = d_bias != nullptr;
+    // a wave addresses its row range through 32-bit buffer offsets (the out-of-range marker sits at the top of that range)
+    const long rows_per_wave = 4 * ((ksteps + a.waves - 1) / a.waves + 1);
+    if ((unsigned long long)rows_per_wave * (unsigned long long)(ldx > ldg ? ldx : ldg) * 4ull >= 0xFFFFFF00ull) return RGCN_ERR_STRIDE;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(rgcn_dw_root_kernel, dim3((a.waves + 3) / 4), dim3(256), 0, s, a);
     if ((st = (int)hipGetLastError()) != 0) return st;

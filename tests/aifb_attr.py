@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE: materialise tests/golden/aifb_attr_config5.npz (generator + provenance: tests/golden/make_aifb_attr.py)
+"""TEST INFRASTRUCTURE: materialise tests/golden/config5/aifb_attr_config5.npz (generator + provenance: tests/golden/config5/make_aifb_attr.py)
 as the N-Triples files the reference's flow reads -- an original graph, three attribute summaries, three node maps -- with
 names whose sorted order is the id order of the fixture."""
 import os
@@ -12,7 +12,7 @@ RDF_TYPE = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
 
 
 def load():
-    return np.load(os.path.join(GOLDEN_DIR, "aifb_attr_config5.npz"))
+    return np.load(os.path.join(GOLDEN_DIR, "config5", "aifb_attr_config5.npz"))
 
 
 def write_dataset(root: str):

@@ -1,4 +1,4 @@
-"""Generator of tests/golden/aifb_attr_config5.npz (run once in the build container; the reference is not on the GPU box).
+"""Generator of tests/golden/config5/aifb_attr_config5.npz (run once in the build container; the reference is not on the GPU box).
 
 BASELINE.json config 5 -- "AIFB attr-summary pre-train -> full-graph transfer" -- needs the AIFB original graph, which the
 reference does not ship (graphs/AIFB/AIFB_complete.nt is listed in .MISSING_LARGE_BLOBS).  It DOES ship the three attribute

@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(768) probe(long long* cyc, int iters, float* s
             if (MODE == 8) { MFMA32(d0, a, b); continue; }
             if (MODE == 9) { MFMA(c0, a, b); VFMA(f0, a, b); VFMA(f1, a, b); MFMA(c1, a, b); VFMA(f2, a, b); VFMA(f3, a, b); continue; }
             if (MODE == 10) { MFMA(c0, a, b); VPKFMA(p0, p1, p2); MFMA(c1, a, b); VPKFMA(p3, p1, p2); continue; }
+            if (MODE == 11) { MFMA(c0, a, b); MFMA(c0, a, b); continue; }       // ONE dependent chain
             MFMA(c0, a, b);
             if (MODE == 1) { VADD(f0); }
             if (MODE == 2) { VADD(f0); VADD(f1); VADD(f2); }
@@ -106,5 +107,6 @@ int main() {
     run<8>("8 MFMA 32x32x2 (same flops as 16 16x16x4)", d, sink);
     run<9>("16 MFMA + 2 v_fma after each (32)", d, sink);
     run<10>("16 MFMA + 1 v_pk_fma after each (16)", d, sink);
+    run<11>("16 MFMA on ONE dependent chain", d, sink);
     return 0;
 }
