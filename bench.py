@@ -47,6 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), 155 measured
 # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE, then WRITE_SIZE; gfx950 correction): counters
 # cannot be read inside this process, so `roofline.traffic` quotes the newest committed pass and names it
@@ -188,6 +189,9 @@ def main():
     ap.add_argument("--no-ladder", action="store_true")
     ap.add_argument("--split-precision", action="store_true",
                     help="forward / dX on the bf16x3 split-precision kernel and layout-1 plans (default: exact-fp32 MFMA kernel)")
+    ap.add_argument("--split-producers", dest="split_producers", action="store_true", default=None,
+                    help="forward / dX on the bf16x3 kernel whose producer waves split the rows (fp32-equivalent; tile 224)")
+    ap.add_argument("--no-split-producers", dest="split_producers", action="store_false")
     args = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -217,6 +221,8 @@ def main():
     ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, d, d, dev)
     conv = RGCNConv(d, d, r).to(dev)
     conv.split_precision = bool(args.split_precision)
+    if args.split_producers is not None:
+        conv.split_producers = bool(args.split_producers)
     with torch.no_grad():
         conv.weight.copy_(weight)
         conv.root.copy_(root)
@@ -305,6 +311,9 @@ def main():
     psb = [(_lib.plan_struct(p), p) for p in bps]
 
     kf = conv.kernel_flags
+    split_producers = world == 1 and conv._use_split_producers(fps[0].chunk) and fps[0].layout == 0
+    if split_producers:
+        kf |= _lib.FLAG_SPLIT_PRODUCERS
 
     def run_fwd():
         for ps, p in psf:
@@ -347,6 +356,8 @@ def main():
     tile_ms = kernel_ms["fwd"] + kernel_ms["dx"]
     if tile_ms >= kernel_ms["dw"]:
         kname, prof_name = "rgcn_tile_kernel (fwd + dX launches)", "rgcn::rgcn_tile_kernel<64, 64"
+        if split_producers:
+            kname, prof_name = "rgcn_tile3p_kernel (fwd + dX launches)", "rgcn::rgcn_tile3p_kernel"
         kbytes, kflops, kms = (alg["fwd"] + alg["dx"]) / 2, (flops["fwd"] + flops["dx"]) / 2, tile_ms / 2
     else:
         kname, prof_name = "dW launches", "rgcn::rgcn_dw_tile_kernel" if psd is not None else "rgcn::rgcn_dw_direct_kernel"
@@ -356,6 +367,9 @@ def main():
     # Which roof binds: the kernels contract in exact fp32 on the matrix cores (tolerance 1e-5 rules out bf16), whose
     # dense peak is 1/16 of bf16's -- at 64 -> 64 the contraction needs more time at its peak than the gather at HBM's
     t_hbm, t_mfma = kbytes / (HBM_PEAK_GBS * 1e9), kflops / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    if split_producers and tile_ms >= kernel_ms["dw"]:
+        # six bf16 products per fp32 product at the dense bf16 MFMA peak (2.5 PFLOP/s): the gathers bind, not the contraction
+        t_mfma = 6.0 * kflops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
     traffic, traffic_source = None, None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
@@ -396,7 +410,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            # fp32 in, fp32 out, fp32 accumulation; with the producer-split kernel the contraction's fp32 operands are split
+            # into three bf16 pieces each (24 significant bits kept) and multiplied on bf16 MFMAs: fp32-equivalent
+            "dtype": "f32 (contraction: bf16x3 split of fp32 operands, fp32 accumulate)" if split_producers else "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic {n} nodes / {e} edges / {r} relations, {d}->{d} fp32, "
                                    f"full-graph layer fwd+bwd (BASELINE.json configs[3])",

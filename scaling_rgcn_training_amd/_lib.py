@@ -26,7 +26,7 @@ EXPORTS = (
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT, FLAG_EXACT_FP32, FLAG_DW_ROOT_ONLY = 1, 2, 4, 8, 16
+FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT, FLAG_EXACT_FP32, FLAG_DW_ROOT_ONLY, FLAG_SPLIT_PRODUCERS = 1, 2, 4, 8, 16, 32
 
 
 class RgcnPlanStruct(C.Structure):

@@ -40,6 +40,10 @@ def _rows16(t: Tensor, width: int) -> Tensor:
 _ENV_TILE = int(os.environ["RGCN_TILE"]) if "RGCN_TILE" in os.environ else None
 _ENV_CHUNK = int(os.environ["RGCN_CHUNK"]) if "RGCN_CHUNK" in os.environ else None
 _SPLIT_PRECISION_DEFAULT = os.environ.get("RGCN_SPLIT_PRECISION", "0") == "1"
+# forward / dX on the bf16 x 3 kernel whose PRODUCER waves split the gathered rows (csrc/rgcn_tile3p.hip):
+# fp32-equivalent arithmetic; layers padded to 64 x 64 on graphs dense enough for 128-slot chunks.  "1" / "0" / "auto"
+_SPLIT_PRODUCERS_DEFAULT = os.environ.get("RGCN_SPLIT_PRODUCERS", "0")
+SPLIT_PRODUCERS_TILE = 224       # the largest tile whose fp32 accumulator fits beside the kernel's two 48 KiB ring slots
 DW_TILES_MIN_EDGES = 4_000_000
 
 _ACT_CODES = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID}
@@ -327,6 +331,8 @@ class RGCNConv(nn.Module):
         # (10.9 vs 10.6 ms per launch at the headline config).
         self.split_precision = _SPLIT_PRECISION_DEFAULT
         self.dw_tiles = True      # d_weight by the tile-major kernel where it applies (_plans); False: relation-major kernels
+        # forward / dX on the producer-split bf16 x 3 kernel where it applies (64 x 64, 128-slot chunks, single GPU)
+        self.split_producers = _SPLIT_PRODUCERS_DEFAULT == "1"
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
             self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
@@ -381,6 +387,8 @@ class RGCNConv(nn.Module):
         e = int(edge_type.shape[0])
         tile, chunk = layout_for(self.in_channels, self.out_channels, n, e, self.num_relations)
         split = self.split_precision and split_for(self.in_channels, self.out_channels, n, e, self.num_relations, tile, chunk)
+        if self._use_split_producers(chunk) and not split:
+            tile = min(tile, SPLIT_PRODUCERS_TILE)
         if self.dist is None:
             # the tile-major weight-gradient kernel: 64 x 64 layers with few relations on graphs large enough to fill it
             from .plan import padded_width
@@ -390,6 +398,11 @@ class RGCNConv(nn.Module):
                                       dw_tiles=dw_tiles)
         from .dist import cached_rank_plans
         return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split)
+
+    def _use_split_producers(self, chunk: int) -> bool:
+        from .plan import padded_width
+        return (self.split_producers and self.dist is None and chunk == 128 and not _ENV_TILE
+                and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None, *,
                 _activation: Optional[str] = None, _input_relu: bool = False,
@@ -406,9 +419,11 @@ class RGCNConv(nn.Module):
         if x.dim() != 2 or x.shape[1] != self.in_channels:
             raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
         plans = self._plans(x, edge_index, edge_type)
+        flags = self.kernel_flags
+        if self.dist is None and self._use_split_producers(plans.fwd.chunk) and plans.fwd.layout == 0:
+            flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx only; the library falls back where it does not fit
         return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist,
-                                  _activation, _input_relu, _grad_premasked and _activation == "relu",
-                                  self.kernel_flags)
+                                  _activation, _input_relu, _grad_premasked and _activation == "relu", flags)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, "

@@ -1,0 +1,513 @@
+// rgcn_tile3p.hip -- forward / dX of the R-GCN layer for gfx950 with the contraction on bf16 MFMAs and the operand split
+// done ONCE per gathered row, by the PRODUCER waves (64 -> 64 layers, 128-slot chunks, layout-0 plans).
+//
+// Replaces the same arithmetic as rgcn_tile_kernel (torch_geometric.nn.RGCNConv.forward and its dX: reference
+// model/layers.py:21,23, model/modelTrainer.py:66) and keeps its structure -- 4 producer + 4 consumer waves per workgroup,
+// a two-slot ring in LDS, the fp32 accumulator tile in LDS, Y^T accumulate, run-sum path for repeated destinations -- with
+// two changes that DESIGN.md 4.5 / 4.6 derive from measurements:
+//   * x W = (xh + xm + xl)(Wh + Wm + Wl) with bf16 pieces and the six products hh, hm, mh, hl, lh, mm on
+//     v_mfma_f32_16x16x32_bf16: 24 significant bits on both operands, i.e. fp32-equivalent (error against float64 no larger
+//     than the sequential fp32 chain's), for 2.7x fewer cycles of the SIMD's arithmetic pipe than v_mfma_f32_16x16x4_f32;
+//   * the 3-way split of x (5.5 vector instructions per element) is what killed that gain when the CONSUMERS did it per
+//     row tile and per wave (rgcn_tile3_kernel).  Here the producers gather rows into REGISTERS (buffer loads, two chunks
+//     ahead), split them once and write three bf16 planes into the ring; their vector work overlaps the consumers' bf16
+//     MFMAs on the shared SIMD (tools/probes/mfma_cross_wave_overlap.hip: a VALU wave slows 1.3x beside bf16 MFMAs, the
+//     MFMA wave not at all).  W is split at pack time (rgcn_pack3_kernel's planes, already part of the packed weights).
+// Ring slot: [plane 0..2][128 rows][64 bf16] = 48 KiB (16-byte pieces of a row XOR-swizzled by (row >> 1) & 7 so that
+// the consumers' ds_read_b128 of 16 rows x 4 k-groups are conflict free); two slots + the [tile + 1][68] fp32 accumulator
+// fit 160 KiB up to tile = 224.
+#include <type_traits>
+#include "rgcn_common.h"
+#include "rgcn_tile_common.h"
+
+namespace rgcn {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// timing-only ablations of diagnostic builds (wrong results): 1 producers load nothing, 2 consumers skip their MFMAs,
+// 4 consumers skip the accumulator read-modify-write, 8 producers skip the split (planes = raw halves)
+#ifndef RGCN_P3_ABL
+#define RGCN_P3_ABL 0
+#endif
+// Diagnostic build only (-DRGCN_P3_STAMPS, tools/debug/p3_stamps.py): per-phase cycle sums of producer wave 0 and consumer
+// wave 4 of every workgroup, written to a buffer no other code reads.
+#ifdef RGCN_P3_STAMPS
+__device__ unsigned long long* g_p3_stamps = nullptr;
+__device__ __forceinline__ unsigned long long p3_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define P3S(v) const unsigned long long v = p3_stamp()
+#define P3A(acc, a, b) acc += (b) - (a)
+#else
+#define P3S(v)
+#define P3A(acc, a, b)
+#endif
+// row tiles whose operands the consumers read ahead of the one they multiply (LDS round trip under load: 300-450 cycles,
+// 12 bf16 MFMAs: ~200)
+#ifndef RGCN_P3_LA
+#define RGCN_P3_LA 2
+#endif
+
+constexpr int kP3Threads = 512;                          // 4 producer + 4 consumer waves
+constexpr int kP3CH = 128;                               // rows of a ring slot == plan chunk
+constexpr int kP3PlaneBytes = kP3CH * 128;               // one bf16 plane of a slot
+constexpr int kP3SlotBytes = 3 * kP3PlaneBytes;
+constexpr int kP3LDO = kAccStride<64>;
+constexpr int kP3FragsPerRel = 2 * 3 * 2 * 2;            // rgcn_pack3_kernel: [column half c][plane][column tile ct][k-step s]
+
+__device__ __forceinline__ unsigned p3_cvt_pk_bf16(float lo, float hi) {      // RNE, lo -> bits 0..15, hi -> bits 16..31
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// ---- producers ----------------------------------------------------------------------------------------------------
+// Wave pw moves rows 32 pw .. 32 pw + 31 of every chunk: 8 buffer loads of 4 rows x 256 B (lane = 16-byte piece c of row
+// rq), two chunks ahead in registers; split; 3 x 8 ds_write_b64.  The chunk's weights / run metadata go by LDS-DMA (one
+// 256-byte dma4 per wave and chunk).
+struct P3Rows {     // what one producer batch loads: set j % 3 holds chunk j
+    f32x4 v[8];    // the wave's 32 rows of chunk j (lane: 16-byte piece c of row 4 i + rq)
+    int meta;      // this lane's word of chunk j's weights (waves 0, 1) or run metadata (waves 2, 3)
+    int idx;       // row indices of chunk j + 2 (lanes 0..31)
+};
+
+// Every vector-memory operation of a producer wave is an inline-asm load into registers, waited for by ONE s_waitcnt
+// vmcnt(0) at the top of the next iteration, BEFORE anything new is issued -- a wait that names the loaded registers as
+// operands, so that no use of them can be scheduled above it.  Left to hipcc the waits were wrong for this pipeline twice
+// over: (1) with the chunk's metadata on LDS-DMA it put vmcnt(0) in front of every LDS store ("a DMA into LDS may be
+// pending"), i.e. behind the gathers just issued; (2) without any DMA its counted waits for the loop-carried row registers
+// still came out as vmcnt(8..0) behind the new gathers.  Either way the wave waited for loads it had just issued.
+// Batches are issued TWO iterations before they are used (three register sets): with the MFMAs at bf16 rate an iteration
+// is shorter than a trip to memory, and a one-iteration lead left the whole workgroup waiting for the next chunk's INDEX
+// load -- 5.8 of 9.7 ms with every other cost ablated away.
+// Iteration it, wave pw: [wait until only the youngest batch is outstanding: set (it + 1) % 3 = rows + metadata of chunk
+// it + 1 and the indices of chunk it + 3] [issue into set it % 3: rows + metadata of chunk it + 3, indices of chunk it + 5]
+// [split + store chunk it + 1] [barrier].
+__device__ __forceinline__ void p3_load_rows(f32x4& dst, i32x4 rsrc, unsigned voff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void p3_load_int(int& dst, const int* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding; the batch names its registers as operands so
+// that no use of them can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void p3_wait_batch(P3Rows& r) {
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+                   "+v"(r.meta), "+v"(r.idx)
+                 : "n"(N)
+                 : "memory");
+}
+
+__device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, float* wring, int* dring, int c0, int nch,
+                                                 int lane, int pw) {
+    const int c = lane & 15, rq = lane >> 4;
+    // raw buffer descriptor of x (stride 0, offen addressing, range check on num_records: rgcn_common.h make_rsrc)
+    const unsigned long long xb = (unsigned long long)a.x;
+    i32x4 rsrc;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)((xb >> 32) & 0xFFFFull));
+    rsrc[2] = __builtin_amdgcn_readfirstlane((int)a.x_bytes);
+    rsrc[3] = 0x00020000;
+    const unsigned coff = c < a.din4 ? (unsigned)c * 16u : 0xFFFFFFF0u;      // beyond the width: out of range -> zeros
+    const unsigned rowb = c < a.din4 ? (unsigned)a.ldx * 4u : 0u;
+    auto idx_ptr = [&](int k) {
+        const int kk = k < nch ? k : nch - 1;
+        return a.slot_src + (size_t)(c0 + kk) * kP3CH + 32 * pw + (lane & 31);
+    };
+    auto issue_loads = [&](P3Rows& r, int idxv) {
+        int idx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) idx[i] = __builtin_amdgcn_ds_bpermute((4 * i + rq) * 4, idxv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (RGCN_P3_ABL & 1) {
+                r.v[i] = f32x4{(float)idx[i], 1.f, 2.f, 3.f};
+                continue;
+            }
+            p3_load_rows(r.v[i], rsrc, __umul24((unsigned)idx[i], rowb) + coff);
+        }
+    };
+    const int half = pw & 1;
+    const int* meta_src = (pw < 2 ? (const int*)a.slot_w : a.slot_acc) + 64 * half + lane;
+    int* meta_dst = (pw < 2 ? (int*)wring : dring) + 64 * half + lane;
+    auto issue_meta = [&](P3Rows& r, int k) { p3_load_int(r.meta, meta_src + (size_t)(c0 + k) * kP3CH); };
+    auto store_meta = [&](const P3Rows& r, int k) { meta_dst[(k & 1) * kP3CH] = r.meta; };
+    auto split_store = [&](const P3Rows& r, int k) {
+        char* slot = ring + (k & 1) * kP3SlotBytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 32 * pw + 4 * i + rq;
+            float x0 = r.v[i][0], x1 = r.v[i][1], x2 = r.v[i][2], x3 = r.v[i][3];
+            if (RGCN_P3_ABL & 8) {
+                char* p8 = slot + row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + ((c & 1) << 3);
+                *(uint2*)p8 = make_uint2(__float_as_uint(x0), __float_as_uint(x1));
+                *(uint2*)(p8 + kP3PlaneBytes) = make_uint2(__float_as_uint(x2), __float_as_uint(x3));
+                *(uint2*)(p8 + 2 * kP3PlaneBytes) = make_uint2(__float_as_uint(x0), __float_as_uint(x3));
+                continue;
+            }
+            const unsigned h0 = p3_cvt_pk_bf16(x0, x1), h1 = p3_cvt_pk_bf16(x2, x3);
+            x0 -= __uint_as_float(h0 << 16);
+            x1 -= __uint_as_float(h0 & 0xFFFF0000u);
+            x2 -= __uint_as_float(h1 << 16);
+            x3 -= __uint_as_float(h1 & 0xFFFF0000u);
+            const unsigned m0 = p3_cvt_pk_bf16(x0, x1), m1 = p3_cvt_pk_bf16(x2, x3);
+            x0 -= __uint_as_float(m0 << 16);
+            x1 -= __uint_as_float(m0 & 0xFFFF0000u);
+            x2 -= __uint_as_float(m1 << 16);
+            x3 -= __uint_as_float(m1 & 0xFFFF0000u);
+            const unsigned l0 = p3_cvt_pk_bf16(x0, x1), l1 = p3_cvt_pk_bf16(x2, x3);
+            char* p = slot + row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + ((c & 1) << 3);
+            if (RGCN_P3_ABL & 32) {      // timing only: no plane stores
+                asm volatile("" ::"v"(h0), "v"(h1), "v"(m0), "v"(m1), "v"(l0), "v"(l1), "v"(p));
+                continue;
+            }
+            *(uint2*)p = make_uint2(h0, h1);
+            *(uint2*)(p + kP3PlaneBytes) = make_uint2(m0, m1);
+            *(uint2*)(p + 2 * kP3PlaneBytes) = make_uint2(l0, l1);
+        }
+    };
+    auto issue_batch = [&](P3Rows& r, int j, int idx_rows) {      // rows + metadata of chunk j, indices of chunk j + 2: 10 loads
+        issue_loads(r, idx_rows);
+        issue_meta(r, j < nch ? j : nch - 1);
+        p3_load_int(r.idx, idx_ptr(j + 2));
+    };
+    P3Rows r0, r1, r2;
+    auto clear = [&](P3Rows& r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r.meta = r.idx = 0;
+    };
+    clear(r0); clear(r1); clear(r2);
+    // prologue: indices of chunks 0 and 1, then the batches of chunks 0, 1, 2
+    p3_load_int(r1.idx, idx_ptr(0));
+    p3_load_int(r2.idx, idx_ptr(1));
+    p3_wait_batch<0>(r1);
+    p3_wait_batch<0>(r2);
+    const int i0 = r1.idx, i1 = r2.idx;
+    issue_batch(r0, 0, i0);                        // + indices of chunk 2
+    issue_batch(r1, 1, i1);                        // + indices of chunk 3
+    p3_wait_batch<10>(r0);                         // all but the youngest batch: rows of chunk 0, indices of chunk 2
+    issue_batch(r2, 2, r0.idx);                    // + indices of chunk 4
+    split_store(r0, 0);
+    store_meta(r0, 0);
+    wg_barrier();                                  // chunk 0 (and the accumulator init) visible
+    // (batches are issued for chunks past the end too, from clamped addresses: the count of operations in flight stays what
+    // the waits assume; two or three redundant batches per tile)
+#ifdef RGCN_P3_STAMPS
+    unsigned long long sp_wait = 0, sp_issue = 0, sp_split = 0, sp_bar = 0;
+#endif
+    auto step = [&](int it, P3Rows& tgt, P3Rows& src) {      // tgt = set it % 3, src = set (it + 1) % 3
+        P3S(q0);
+        p3_wait_batch<10>(src);
+        __builtin_amdgcn_sched_barrier(0);
+        P3S(q1);
+        if (it + 1 < nch) issue_batch(tgt, it + 3, src.idx);
+        __builtin_amdgcn_sched_barrier(0);
+        P3S(q2);
+        if (it + 1 < nch) {
+            split_store(src, it + 1);
+            store_meta(src, it + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        P3S(q3);
+        wg_barrier();
+        P3S(q4);
+        P3A(sp_wait, q0, q1); P3A(sp_issue, q1, q2); P3A(sp_split, q2, q3); P3A(sp_bar, q3, q4);
+    };
+    for (int it = 0; it < nch; it += 3) {
+        step(it, r0, r1);
+        if (it + 1 < nch) step(it + 1, r1, r2);
+        if (it + 2 < nch) step(it + 2, r2, r0);
+    }
+    wait_vmcnt<0>();
+#ifdef RGCN_P3_STAMPS
+    if (g_p3_stamps && pw == 0 && lane == 0) {
+        unsigned long long* o = g_p3_stamps + (size_t)blockIdx.x * 16;
+        o[0] = sp_wait; o[1] = sp_issue; o[2] = sp_split; o[3] = sp_bar; o[4] = nch;
+    }
+#endif
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileArgs a) {
+    constexpr int LDO = kP3LDO;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* out_lds = lds;                                          // [tile + 1][LDO]  (row `tile`: dummy)
+    char* ring = (char*)(lds + (a.tile + 1) * LDO);                // [2][3][128][128 B]
+    float* wring = (float*)(ring + 2 * kP3SlotBytes);              // [2][128]
+    int* dring = (int*)(wring + 2 * kP3CH);                        // [2][128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // one tile per workgroup (walking several tiles per workgroup, as rgcn_tile_kernel does, measured no faster here)
+    const int tile = blockIdx.x;
+    const int c0 = ldc(a.tile_ptr, tile);
+    const int nch = ldc(a.tile_ptr, tile + 1) - c0;
+
+    for (int i = tid; i < (a.tile + 1) * LDO; i += kP3Threads) {
+        const int col = i % LDO;
+        out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
+    }
+
+    if (wave >= 4) {
+        // ---- consumers: wave cw owns output columns 16 cw .. 16 cw + 15 of every row ----------------------------------
+        const int cw = wave - 4;
+        const int rowl = lane & 15, kq = lane >> 4;
+        const unsigned col4_bytes = (unsigned)(16 * cw + 4 * kq) * 4u;     // Y^T layout: four consecutive columns of row rowl
+        const unsigned col1_bytes = (unsigned)(16 * cw + rowl) * 4u;       // Y layout: column rowl of rows 4 kq + i
+        // W planes of this wave's column tile: packed3[((((rel * 2 + c) * 3 + pl) * 2 + ct) * 2 + s) * 64 + lane]
+        const uint4* wp4 = (const uint4*)a.wp + (size_t)((cw >> 1) * 3 * 2 * 2 + (cw & 1) * 2) * 64 + lane;
+        auto wptr = [&](int rel, int pl) { return (const f32x4*)(wp4 + ((size_t)rel * kP3FragsPerRel + pl * 4) * 64); };
+        f32x4 wcur[3][2], wnext[3][2];
+        int rel_cur = ldc(a.chunk_rel, c0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            wcur[pl][0] = wptr(rel_cur, pl)[0];
+            wcur[pl][1] = wptr(rel_cur, pl)[64];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire these loads in the compiler's scoreboard
+        int cnt_pre = ldc(a.chunk_cnt, c0);
+        int flags_pre = ldc(a.chunk_flags, c0);
+        int rel_n1 = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
+        int rel_n2 = nch > 2 ? ldc(a.chunk_rel, c0 + 2) : rel_n1;
+        auto prefetch_rel = [&](int rel) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                prefetch16<0>(wnext[pl][0], wptr(rel, pl));
+                prefetch16<1024>(wnext[pl][1], wptr(rel, pl));
+            }
+        };
+        bool pending = rel_n1 != rel_cur;
+        if (pending) prefetch_rel(rel_n1);
+        wg_barrier();
+#ifdef RGCN_P3_STAMPS
+        unsigned long long sc_meta = 0, sc_comp = 0, sc_swap = 0, sc_bar = 0;
+#endif
+        for (int it = 0; it < nch; ++it) {
+            P3S(t0);
+            const int chunk = c0 + it;
+            const int buf = it & 1;
+            const int cnt = cnt_pre;
+            const int flags = flags_pre & 0xFF;
+            const int rel_next = rel_n1;
+            const int rel_next2 = rel_n2;
+            if (it + 1 < nch) {
+                cnt_pre = ldc(a.chunk_cnt, chunk + 1);
+                flags_pre = ldc(a.chunk_flags, chunk + 1);
+            }
+            rel_n1 = rel_n2;
+            if (it + 3 < nch) rel_n2 = ldc(a.chunk_rel, chunk + 3);
+            const bool swap_b = pending;
+            const int nrt = (cnt + 15) >> 4;
+#ifdef RGCN_P3_STAMPS
+            asm volatile("" ::"s"(cnt), "s"(rel_next), "s"(flags));
+#endif
+            P3S(t1);
+            // this lane's operand addresses of row tile 0: plane pl at + pl * 16 KiB, row tile t at + t * 2 KiB (immediates)
+            const char* xrow[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                xrow[s] = ring + buf * kP3SlotBytes + rowl * 128 + (((4 * s + kq) ^ ((rowl >> 1) & 7)) << 4);
+            const float* wb = wring + buf * kP3CH;
+            const int* db = dring + buf * kP3CH;
+            struct Ops {
+                bf16x8 pl[3][2];    // [plane][k-step]: 8 bf16 of row rowl, k = 32 s + 8 kq + (0..7)
+                float w1;
+                int d1;
+            };
+            auto load_ops = [&](Ops& o, int t) {
+                o.w1 = wb[t * 16 + rowl];
+                o.d1 = db[t * 16 + rowl];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        if (RGCN_P3_ABL & 16) {      // timing only: no operand reads
+                            o.pl[pl][s] = __builtin_bit_cast(bf16x8, f32x4{o.w1, 1.f, 2.f, 3.f});
+                            continue;
+                        }
+                        o.pl[pl][s] = *(const bf16x8*)(xrow[s] + pl * kP3PlaneBytes + t * 2048);
+                    }
+            };
+            auto acc_ptr = [&](int d, unsigned col_bytes) -> float* {
+                return (float*)((char*)out_lds + (__umul24((unsigned)d, (unsigned)(LDO * 4)) + col_bytes));
+            };
+            constexpr int px[6] = {0, 0, 1, 0, 2, 1}, pwl[6] = {0, 1, 0, 2, 0, 1};      // x plane, W plane: hh hm mh hl lh mm
+            // six products of one half (k-step s) of a row tile, Y^T orientation: a lane ends with 4 consecutive columns of a row
+            auto mfma_half = [&](const Ops& o, f32x4 y, int s) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    if (RGCN_P3_ABL & 2) {
+                        y += __builtin_bit_cast(f32x4, o.pl[px[q]][s]);
+                        continue;
+                    }
+                    y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[pwl[q]][s]), o.pl[px[q]][s], y, 0, 0, 0);
+                }
+                return y;
+            };
+            // ---- chunks without repeated destinations inside a row tile: straight-line, operands LA tiles ahead ------------
+            // (Reading tile t + 1's accumulator row BEFORE tile t is stored -- with the lane's own previous value forwarded
+            // where the two addresses match -- was tried to break the store -> read -> FMA -> store chain: 10.3 ms against
+            // 9.7, and not sufficient as it stood: a run of equal destinations as long as the group's tile count wraps and puts
+            // the same destination at place p + 1 of tile t and place p of tile t + 1.  The launch is bound by LDS traffic and
+            // the producers' split, not by this chain: DESIGN.md 4.7.)
+            auto consume = [&](auto nrt_c) {
+                constexpr int NRT = decltype(nrt_c)::value;
+                constexpr int LA = RGCN_P3_LA;
+                Ops o[NRT];
+                f32x4 y[NRT], old[NRT];
+                float* dst[NRT];
+#pragma unroll
+                for (int t = 0; t < LA; ++t)
+                    if (t < NRT) load_ops(o[t], t);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int step = 0; step <= NRT; ++step) {
+                    if (step < NRT) {
+                        if (step + LA < NRT) load_ops(o[step + LA], step + LA);
+                        y[step] = mfma_half(o[step], f32x4{0.f, 0.f, 0.f, 0.f}, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // one group of vector instructions per tile: store of tile step - 1, then address + accumulator read of
+                    // tile step (in this order: consecutive tiles may scatter into the same accumulator row)
+                    if (RGCN_P3_ABL & 4) {
+                        if (step >= 1) asm volatile("" ::"v"(y[step - 1]), "v"(o[step - 1].w1), "v"(o[step - 1].d1));
+                        if (step < NRT) old[step] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else if (step >= 1) {
+                        *(f32x4*)dst[step - 1] = y[step - 1] * o[step - 1].w1 + old[step - 1];
+                    }
+                    if (step < NRT && !(RGCN_P3_ABL & 4)) {
+                        dst[step] = acc_ptr(o[step].d1, col4_bytes);
+                        old[step] = *(const f32x4*)dst[step];
+                    }
+                    if (step < NRT) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        y[step] = mfma_half(o[step], y[step], 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            // ---- chunks with a repeated destination in some row tile: tile by tile; a flagged tile takes the Y orientation
+            // and the run-sum product Z = P Y + old in exact fp32 (rgcn_tile_kernel stage B)
+            auto process_slow = [&](int t) {
+                Ops o;
+                load_ops(o, t);
+                const bool dup = (flags >> t) & 1;
+                if (!dup) {
+                    float* d = acc_ptr(o.d1, col4_bytes);
+                    const f32x4 oldv = *(const f32x4*)d;
+                    f32x4 yv = mfma_half(o, f32x4{0.f, 0.f, 0.f, 0.f}, 0);
+                    yv = mfma_half(o, yv, 1);
+                    *(f32x4*)d = yv * o.w1 + oldv;
+                    return;
+                }
+                const f32x4 w4 = *(const f32x4*)(wb + t * 16 + 4 * kq);
+                const i32x4 d4 = *(const i32x4*)(db + t * 16 + 4 * kq);
+                f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        yv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.pl[px[q]][s], __builtin_bit_cast(bf16x8, wcur[pwl[q]][s]), yv, 0, 0, 0);
+                float* d[4];
+                float pm[4];
+                f32x4 oldv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d[i] = acc_ptr(d4[i], col1_bytes);
+                    pm[i] = ((unsigned)d4[i] >> 24) == (unsigned)rowl ? w4[i] : 0.f;
+                    oldv[i] = *d[i];
+                }
+                f32x4 z1 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], yv[0], oldv, 0, 0, 0);
+                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], yv[1], z1, 0, 0, 0);
+                z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], yv[2], z0, 0, 0, 0);
+                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], yv[3], z1, 0, 0, 0);
+                const f32x4 v = z0 + z1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *d[i] = v[i];
+            };
+            using std::integral_constant;
+            if (flags == 0) {
+                switch (nrt) {
+                    case 1: consume(integral_constant<int, 1>{}); break;
+                    case 2: consume(integral_constant<int, 2>{}); break;
+                    case 3: consume(integral_constant<int, 3>{}); break;
+                    case 4: consume(integral_constant<int, 4>{}); break;
+                    case 5: consume(integral_constant<int, 5>{}); break;
+                    case 6: consume(integral_constant<int, 6>{}); break;
+                    case 7: consume(integral_constant<int, 7>{}); break;
+                    case 8: consume(integral_constant<int, 8>{}); break;
+                    default: break;
+                }
+            } else {
+                for (int t = 0; t < nrt; ++t) process_slow(t);
+            }
+            P3S(t2);
+            if (swap_b) {
+                wait_vmcnt<0>();                     // the asm prefetch (this wave's only vector-memory traffic)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    wcur[pl][0] = wnext[pl][0];
+                    wcur[pl][1] = wnext[pl][1];
+                }
+            }
+            rel_cur = rel_next;
+            pending = it + 2 < nch && rel_next2 != rel_next;
+            if (pending) prefetch_rel(rel_next2);
+            P3S(t3);
+            wg_barrier();
+            P3S(t4);
+            P3A(sc_meta, t0, t1); P3A(sc_comp, t1, t2); P3A(sc_swap, t2, t3); P3A(sc_bar, t3, t4);
+        }
+#ifdef RGCN_P3_STAMPS
+        if (g_p3_stamps && cw == 0 && lane == 0) {
+            unsigned long long* o = g_p3_stamps + (size_t)blockIdx.x * 16;
+            o[8] = sc_meta; o[9] = sc_comp; o[10] = sc_swap; o[11] = sc_bar;
+        }
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the consumers is pending when the producer code follows
+    }
+    if (wave < 4) p3_producer_loop(a, ring, wring, dring, c0, nch, lane, wave);
+    tile_epilogue<LDO, false>(a, out_lds, tile, tid, kP3Threads);
+}
+
+// bytes of dynamic LDS at tile size `tile`
+static size_t p3_lds_bytes(int tile) {
+    return sizeof(float) * (size_t)(tile + 1) * kP3LDO + 2 * (size_t)kP3SlotBytes + 2 * kP3CH * 8;
+}
+
+// Launch (called by run_tile in rgcn_kernels.hip when RGCN_FLAG_SPLIT_PRODUCERS is set and the shapes fit): `a.wp` points at
+// the bf16 planes of the packed weights.  Returns RGCN_ERR_LDS / RGCN_ERR_PLAN when it does not apply.
+int launch_tile3p(const TileArgs& a, int n_tiles, void* stream) {
+    if (a.x_bytes == 0) return RGCN_ERR_PLAN;          // buffer-descriptor addressing only
+    const size_t lds = p3_lds_bytes(a.tile);
+    if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute((const void*)rgcn_tile3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) return (int)e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(rgcn_tile3p_kernel, dim3(n_tiles), dim3(kP3Threads), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+#ifdef RGCN_P3_STAMPS
+extern "C" int rgcn_debug_set_p3_stamps(unsigned long long* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p3_stamps), &p, sizeof(p));
+}
+#endif
+
+}  // namespace rgcn

@@ -471,3 +471,53 @@ def test_dw_root_streaming_kernel(dev, rows, din, dout):
     _lib.bwd_dw_root(xd, din, gd, dout, dr2, None)
     _lib.bwd_dw_root(xd, din, gd, dout, None, db2)
     assert torch.equal(dr, dr2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("n,e,r,tile,skew", [(3000, 330000, 3, 224, False), (2000, 200000, 4, 128, True), (5000, 90000, 7, 224, False),
+                                             (800, 120000, 2, 64, True), (40, 300, 2, 16, False)])
+def test_split_producers_kernel_matches_oracle(dev, n, e, r, tile, skew):
+    """The bf16 x 3 forward / dX kernel whose PRODUCER waves split the gathered rows (csrc/rgcn_tile3p.hip; 64 x 64, layout-0
+    plans, 128-slot chunks, tiles up to 224: hubs and duplicate triples so that row tiles repeat destinations and take its
+    run-sum path, chunks of 1 to 8 row tiles, a graph of three tiles) against the float64 oracle under both bounds of
+    oracle/tolerance.py, and against the exact-fp32 kernel on the same plan; bit-reproducible."""
+    from scaling_rgcn_training_amd import _lib
+    din = dout = 64
+    ei, et = O.synthetic_graph(n, e, r, seed=n + r, skew=skew)
+    ei[:, 100:160] = ei[:, 20:80]           # duplicate triples
+    et[100:160] = et[20:80]
+    w, root, bias = O.synthetic_params(r, din, dout, seed=9)
+    g = torch.Generator().manual_seed(17)
+    bias = torch.randn(dout, generator=g) * 0.1
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    res3 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS)
+    _check_layer(res3, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [bf16x3 producers T{tile} n{n}]")
+    res1 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128)
+    for a, b in zip(res3[:2], res1[:2]):
+        assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, float(np.abs(b).max()))
+    assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel
+    again = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS)
+    assert np.array_equal(res3[0], again[0]) and np.array_equal(res3[1], again[1])
+
+
+def test_split_producers_through_the_module(dev):
+    """``RGCNConv.split_producers = True``: plans at the kernel's tile size, forward + backward through autograd against the
+    module's exact-fp32 result, 63 -> 64 (padded input rows) with a fused ReLU and the ReLU mask in the dX store."""
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    n, e, r = 6000, 200000, 5
+    ei, et = O.synthetic_graph(n, e, r, seed=4)
+    g = torch.Generator().manual_seed(3)
+    x = torch.relu(torch.randn(n, 63, generator=g))
+    dg = torch.randn(n, 64, generator=g)
+    outs = []
+    for on in (False, True):
+        torch.manual_seed(0)
+        conv = RGCNConv(63, 64, r).to(dev)
+        conv.split_producers = on
+        xd = x.to(dev).requires_grad_(True)
+        out = conv(xd, ei.to(dev), et.to(dev), _activation="relu", _input_relu=True)
+        out.backward(dg.to(dev))
+        outs.append([t.detach().cpu().numpy() for t in (out, xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad)])
+    for a, b in zip(outs[1], outs[0]):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(b).max())))

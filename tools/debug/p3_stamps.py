@@ -1,0 +1,38 @@
+"""Per-phase cycle shares of rgcn_tile3p_kernel's producer / consumer loops (stamp build of csrc/rgcn_tile3p.hip only,
+linked against the product objects).  Usage: p3_stamps.py [N E]"""
+import ctypes, os, subprocess, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+B = os.path.join(ROOT, "scaling_rgcn_training_amd", "_build")
+so = os.path.join(ROOT, "gpurun_out", "librgcn_p3stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+H = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+subprocess.run(H + ["-DRGCN_P3_STAMPS", "-c", os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_tile3p.hip"), "-o", so + ".o"], check=True)
+subprocess.run(H + ["-shared", os.path.join(B, "rgcn_kernels.o"), os.path.join(B, "rgcn_dw_root.o"), os.path.join(B, "rgcn_plan.o"), so + ".o", "-o", so], check=True)
+from scaling_rgcn_training_amd import _lib
+_lib.LIB_PATH = so
+lib = _lib.load()
+from scaling_rgcn_training_amd import plan as P
+import bench
+n, e = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10_000_000, 100_000_000)
+dev = torch.device("cuda:0")
+ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, 32, 64, 64, dev)
+plans = P.build_graph_plans_device(ei, et, n, 32, 224, chunk=128, dw_tiles=False)
+fp = plans.fwd
+stamps = torch.zeros(fp.n_tiles * 16, dtype=torch.int64, device=dev)
+lib.rgcn_debug_set_p3_stamps.argtypes = [ctypes.c_void_p]
+assert lib.rgcn_debug_set_p3_stamps(stamps.data_ptr()) == 0
+out = torch.empty(n, 64, device=dev)
+pk = _lib.pack_weights(w, root, False)
+for _ in range(2):
+    stamps.zero_()
+    _lib.fwd(_lib.plan_struct(fp), x, 64, pk, None, out, 64, 0, _lib.FLAG_SPLIT_PRODUCERS)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64)
+nch = s[:, 4].sum()
+print("tiles", fp.n_tiles, "chunks", int(nch))
+for i, nm in ((0, "prod wait batch"), (1, "prod issue batch"), (2, "prod split + store"), (3, "prod barrier"),
+              (8, "cons metadata"), (9, "cons compute"), (10, "cons W swap + prefetch"), (11, "cons barrier")):
+    print(f"{nm:24s} {s[:, i].sum() / nch:9.1f} cycles/chunk")
+print("producer total %.1f  consumer total %.1f" % (s[:, 0:4].sum() / nch, s[:, 8:12].sum() / nch))

@@ -18,6 +18,8 @@ def child():
     dev = torch.device("cuda:0")
     ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, r, 64, 64, dev)
     tile, chunk = P.choose_layout(n, e, r, 64, 64)
+    tile = int(os.environ.get("VT_TILE", tile))
+    kflags = int(os.environ.get("VT_FLAGS", 0))
     plans = P.build_graph_plans_device(ei, et, n, r, tile, chunk=chunk, dw_tiles="dw" in which)
     del ei, et
 
@@ -38,12 +40,12 @@ def child():
     if "fwd" in which:
         pk = _lib.pack_weights(w, root, False)
         ps = _lib.plan_struct(plans.fwd)
-        m, lo = t(lambda: _lib.fwd(ps, x, 64, pk, bias, out, 64))
+        m, lo = t(lambda: _lib.fwd(ps, x, 64, pk, bias, out, 64, 0, kflags))
         print("  fwd        %.3f ms (min %.3f)  checksum %s" % (m, lo, cs(out)), flush=True)
     if "dx" in which:
         pkt = _lib.pack_weights(w, root, True)
         pst = _lib.plan_struct(plans.bwd)
-        m, lo = t(lambda: _lib.bwd_dx(pst, dg, 64, pkt, out, 64))
+        m, lo = t(lambda: _lib.bwd_dx(pst, dg, 64, pkt, out, 64, None, kflags))
         print("  dx         %.3f ms (min %.3f)  checksum %s" % (m, lo, cs(out)), flush=True)
     if "dw" in which:
         dw, dr, db = torch.empty_like(w), torch.empty_like(root), torch.empty(64, device=dev)
