@@ -311,7 +311,7 @@ def main():
     psb = [(_lib.plan_struct(p), p) for p in bps]
 
     kf = conv.kernel_flags
-    split_producers = world == 1 and conv._use_split_producers(fps[0].chunk) and fps[0].layout == 0
+    split_producers = bool(fps) and conv._use_split_producers(fps[0].chunk) and fps[0].layout == 0
     if split_producers:
         kf |= _lib.FLAG_SPLIT_PRODUCERS
 
@@ -397,31 +397,33 @@ def main():
                      "target_frac": 0.40, "ms_per_step_at_target": step_bytes / (0.40 * HBM_PEAK_GBS * 1e9) * 1e3 / world}
 
     rec = None
-    # Secondary measurement, never the headline `value`: the same step with forward / dX on the producer-split bf16 x 3 kernel
-    # (RGCNConv.split_producers; fp32-equivalent arithmetic, own plans at tile 224), on the same box right after the main run
+    # Secondary measurement, never the headline `value`: the same step with the OTHER forward / dX kernel -- exact-fp32 MFMA
+    # (rgcn_tile_kernel) when the default producer-split bf16 x 3 kernel ran above, and vice versa -- on the same box right
+    # after the main run, with its own plans
     alt = None
-    if world == 1 and not split_producers and (n, e, r, d) == HEADLINE and not args.no_ladder:
+    if world == 1 and (n, e, r, d) == HEADLINE and not args.no_ladder and not args.split_precision:
+        main_mode = conv.split_producers
         try:
-            conv.split_producers = True
-            if conv._use_split_producers(fps[0].chunk):
-                for _ in range(3):
-                    step()
-                torch.cuda.synchronize()
-                aevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
-                for a, b in aevs:
-                    a.record()
-                    step()
-                    b.record()
-                torch.cuda.synchronize()
-                ams = statistics.median(a.elapsed_time(b) for a, b in aevs)
-                alt = {"what": "forward / dX on rgcn_tile3p_kernel (operand split by the producer waves, bf16 x 3 MFMAs, "
-                               "fp32-equivalent); opt-in: RGCNConv.split_producers / RGCN_SPLIT_PRODUCERS=1",
-                       "ms_per_step_median": ams, "steps": 15, "edges_per_s": e / (ams * 1e-3)}
-                log(f"alt (producer-split bf16x3 forward / dX): {ams:.2f} ms/step")
+            conv.split_producers = not main_mode
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            aevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
+            for a, b in aevs:
+                a.record()
+                step()
+                b.record()
+            torch.cuda.synchronize()
+            ams = statistics.median(a.elapsed_time(b) for a, b in aevs)
+            alt = {"what": ("forward / dX on rgcn_tile3p_kernel (operand split by the producer waves, bf16 x 3 MFMAs, fp32-equivalent)"
+                            if conv.split_producers else
+                            "forward / dX on rgcn_tile_kernel (exact-fp32 MFMA; RGCNConv.split_producers = False / RGCN_SPLIT_PRODUCERS=0)"),
+                   "ms_per_step_median": ams, "steps": 15, "edges_per_s": e / (ams * 1e-3)}
+            log(f"alt ({'producer-split bf16x3' if conv.split_producers else 'exact-fp32'} forward / dX): {ams:.2f} ms/step")
         except Exception as err:      # the secondary leg must never take the headline record down
             log(f"alt leg skipped: {err!r}")
         finally:
-            conv.split_producers = False
+            conv.split_producers = main_mode
     if rank == 0:
         rec = {
             "metric": "edges/s per RGCN layer (fwd+bwd)",
@@ -446,7 +448,7 @@ def main():
             "roofline": roofline,
             "roofline_step": roofline_step,
             "kernel_ms": kernel_ms,
-            "alt_split_producers": alt,
+            "alt_forward_kernel": alt,
             "plan_build_s": plan_s,
             "plan_bytes": sum(p.nbytes() for p in fps + bps),
         }

@@ -42,7 +42,7 @@ _ENV_CHUNK = int(os.environ["RGCN_CHUNK"]) if "RGCN_CHUNK" in os.environ else No
 _SPLIT_PRECISION_DEFAULT = os.environ.get("RGCN_SPLIT_PRECISION", "0") == "1"
 # forward / dX on the bf16 x 3 kernel whose PRODUCER waves split the gathered rows (csrc/rgcn_tile3p.hip):
 # fp32-equivalent arithmetic; layers padded to 64 x 64 on graphs dense enough for 128-slot chunks.  "1" / "0" / "auto"
-_SPLIT_PRODUCERS_DEFAULT = os.environ.get("RGCN_SPLIT_PRODUCERS", "0")
+_SPLIT_PRODUCERS_DEFAULT = os.environ.get("RGCN_SPLIT_PRODUCERS", "1")
 SPLIT_PRODUCERS_TILE = 224       # the largest tile whose fp32 accumulator fits beside the kernel's two 48 KiB ring slots
 DW_TILES_MIN_EDGES = 4_000_000
 
@@ -331,7 +331,9 @@ class RGCNConv(nn.Module):
         # (10.9 vs 10.6 ms per launch at the headline config).
         self.split_precision = _SPLIT_PRECISION_DEFAULT
         self.dw_tiles = True      # d_weight by the tile-major kernel where it applies (_plans); False: relation-major kernels
-        # forward / dX on the producer-split bf16 x 3 kernel where it applies (64 x 64, 128-slot chunks, single GPU)
+        # forward / dX on the producer-split bf16 x 3 kernel where it applies (64 x 64, 128-slot chunks, single GPU): fp32-
+        # equivalent arithmetic (24-bit operand significands, exact products, fp32 accumulation), 1 ms per step faster at
+        # the headline config.  False (or RGCN_SPLIT_PRODUCERS=0): the exact-fp32 MFMA kernel everywhere
         self.split_producers = _SPLIT_PRODUCERS_DEFAULT == "1"
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
@@ -385,10 +387,8 @@ class RGCNConv(nn.Module):
     def _plans(self, x: Tensor, edge_index: Tensor, edge_type: Tensor) -> GraphPlans:
         n = x.shape[0]
         e = int(edge_type.shape[0])
-        tile, chunk = layout_for(self.in_channels, self.out_channels, n, e, self.num_relations)
+        tile, chunk = self.layout(n, e)
         split = self.split_precision and split_for(self.in_channels, self.out_channels, n, e, self.num_relations, tile, chunk)
-        if self._use_split_producers(chunk) and not split:
-            tile = min(tile, SPLIT_PRODUCERS_TILE)
         if self.dist is None:
             # the tile-major weight-gradient kernel: 64 x 64 layers with few relations on graphs large enough to fill it
             from .plan import padded_width
@@ -401,8 +401,16 @@ class RGCNConv(nn.Module):
 
     def _use_split_producers(self, chunk: int) -> bool:
         from .plan import padded_width
-        return (self.split_producers and self.dist is None and chunk == 128 and not _ENV_TILE
+        return (self.split_producers and not self.split_precision and chunk == 128 and not _ENV_TILE
                 and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64)
+
+    def layout(self, n_nodes: int, n_edges: int) -> Tuple[int, int]:
+        """(tile, chunk) of this layer's plans on a graph of that size: ``layout_for``, capped at the producer-split kernel's
+        tile where that kernel will run (dist.attach aligns the ranks' node ranges to the same tile)."""
+        tile, chunk = layout_for(self.in_channels, self.out_channels, n_nodes, n_edges, self.num_relations)
+        if self._use_split_producers(chunk):
+            tile = min(tile, SPLIT_PRODUCERS_TILE)
+        return tile, chunk
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None, *,
                 _activation: Optional[str] = None, _input_relu: bool = False,
@@ -420,7 +428,8 @@ class RGCNConv(nn.Module):
             raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
         plans = self._plans(x, edge_index, edge_type)
         flags = self.kernel_flags
-        if self.dist is None and self._use_split_producers(plans.fwd.chunk) and plans.fwd.layout == 0:
+        first = plans.fwd if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
+        if first is not None and self._use_split_producers(first.chunk) and first.layout == 0:
             flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx only; the library falls back where it does not fit
         return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist,
                                   _activation, _input_relu, _grad_premasked and _activation == "relu", flags)

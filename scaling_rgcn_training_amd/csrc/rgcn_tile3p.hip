@@ -51,6 +51,11 @@ __device__ __forceinline__ unsigned long long p3_stamp() {
 #ifndef RGCN_P3_LA
 #define RGCN_P3_LA 2
 #endif
+// 0: round-to-nearest pieces (v_cvt_pk_bf16_f32); 1: the producers split by truncation (v_and / v_sub / v_perm_b32: exact too,
+// but measured 0.25 ms per launch SLOWER: 9.94 against 9.67 ms)
+#ifndef RGCN_P3_TRUNC
+#define RGCN_P3_TRUNC 0
+#endif
 
 constexpr int kP3Threads = 512;                          // 4 producer + 4 consumer waves
 constexpr int kP3CH = 128;                               // rows of a ring slot == plan chunk
@@ -151,17 +156,31 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
                 *(uint2*)(p8 + 2 * kP3PlaneBytes) = make_uint2(__float_as_uint(x0), __float_as_uint(x3));
                 continue;
             }
-            const unsigned h0 = p3_cvt_pk_bf16(x0, x1), h1 = p3_cvt_pk_bf16(x2, x3);
-            x0 -= __uint_as_float(h0 << 16);
-            x1 -= __uint_as_float(h0 & 0xFFFF0000u);
-            x2 -= __uint_as_float(h1 << 16);
-            x3 -= __uint_as_float(h1 & 0xFFFF0000u);
-            const unsigned m0 = p3_cvt_pk_bf16(x0, x1), m1 = p3_cvt_pk_bf16(x2, x3);
-            x0 -= __uint_as_float(m0 << 16);
-            x1 -= __uint_as_float(m0 & 0xFFFF0000u);
-            x2 -= __uint_as_float(m1 << 16);
-            x3 -= __uint_as_float(m1 & 0xFFFF0000u);
-            const unsigned l0 = p3_cvt_pk_bf16(x0, x1), l1 = p3_cvt_pk_bf16(x2, x3);
+            unsigned h0, h1, m0, m1, l0, l1;
+            if (RGCN_P3_TRUNC) {
+                // split by TRUNCATION: h = the top 8 significant bits of x, m = those of x - h, l = x - h - m (8 bits at most):
+                // x = h + m + l exactly, every step a full-rate instruction (v_and / v_sub / v_perm to pack two upper halves);
+                // v_cvt_pk_bf16_f32 issues at about a third of that rate
+                auto pk = [](float lo, float hi) { return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u); };
+                auto top = [](float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); };
+                h0 = pk(x0, x1); h1 = pk(x2, x3);
+                x0 -= top(x0); x1 -= top(x1); x2 -= top(x2); x3 -= top(x3);
+                m0 = pk(x0, x1); m1 = pk(x2, x3);
+                x0 -= top(x0); x1 -= top(x1); x2 -= top(x2); x3 -= top(x3);
+                l0 = pk(x0, x1); l1 = pk(x2, x3);
+            } else {
+                h0 = p3_cvt_pk_bf16(x0, x1); h1 = p3_cvt_pk_bf16(x2, x3);
+                x0 -= __uint_as_float(h0 << 16);
+                x1 -= __uint_as_float(h0 & 0xFFFF0000u);
+                x2 -= __uint_as_float(h1 << 16);
+                x3 -= __uint_as_float(h1 & 0xFFFF0000u);
+                m0 = p3_cvt_pk_bf16(x0, x1); m1 = p3_cvt_pk_bf16(x2, x3);
+                x0 -= __uint_as_float(m0 << 16);
+                x1 -= __uint_as_float(m0 & 0xFFFF0000u);
+                x2 -= __uint_as_float(m1 << 16);
+                x3 -= __uint_as_float(m1 & 0xFFFF0000u);
+                l0 = p3_cvt_pk_bf16(x0, x1); l1 = p3_cvt_pk_bf16(x2, x3);
+            }
             char* p = slot + row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + ((c & 1) << 3);
             if (RGCN_P3_ABL & 32) {      // timing only: no plane stores
                 asm volatile("" ::"v"(h0), "v"(h1), "v"(m0), "v"(m1), "v"(l0), "v"(l1), "v"(p));

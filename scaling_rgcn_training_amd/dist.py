@@ -98,5 +98,5 @@ def attach(module: torch.nn.Module, n_nodes: int, n_edges: int, group=None) -> N
     from .conv import tile_for
     for m in module.modules():
         if isinstance(m, RGCNConv):
-            tile = tile_for(m.in_channels, m.out_channels, n_nodes, n_edges, m.num_relations)
+            tile = m.layout(n_nodes, n_edges)[0]
             m.dist = make_context(n_nodes, tile, group)
