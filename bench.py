@@ -23,8 +23,10 @@ all-gathers and the weight-gradient all-reduce; `comm` reports what they moved a
 
 The JSON line also carries
   roofline       the dominant kernel (HIP-event timed per launch; algorithmic bytes and flops of SURVEY.md 8d /
-                 DESIGN.md; the binding roof is the one that needs more time at its peak -- at 64 -> 64 in exact
-                 fp32 that is the fp32 MFMA peak, with the HBM figures beside it)
+                 DESIGN.md; the binding roof is the one that needs more time at its peak -- HBM for the default
+                 forward / dX kernel, whose contraction runs on bf16 MFMAs over 3-way split fp32 operands; the fp32
+                 MFMA peak for the exact-fp32 kernel (--no-split-producers), with the HBM figures beside it)
+  alt_forward_kernel  the same step with the OTHER forward / dX kernel, timed on the same box right after the main run
   roofline_step  the whole step against HBM: algorithmic bytes of fwd + bwd (92.1 GB at the headline config) / ms_per_step
                  -- the number north_star's ">= 40 % of HBM roofline" refers to
   ladder         GPU edges/s on the smaller rungs of SURVEY.md 8d ((100k, 1M), (1M, 10M), AIFB shape)

@@ -403,7 +403,9 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
                         *(f32x4*)dst[step - 1] = y[step - 1] * o[step - 1].w1 + old[step - 1];
                     }
                     if (step < NRT && !(RGCN_P3_ABL & 4)) {
-                        dst[step] = acc_ptr(o[step].d1, col4_bytes);
+                        // (RGCN_P3_ABL & 64, timing only, wrong results: the 16 lanes of a phase address rows that differ mod
+                        // 16 -- what a conflict-free accumulator order could buy)
+                        dst[step] = acc_ptr((RGCN_P3_ABL & 64) ? ((o[step].d1 & 0xFFFFF0) | rowl) : o[step].d1, col4_bytes);
                         old[step] = *(const f32x4*)dst[step];
                     }
                     if (step < NRT) {
