@@ -71,8 +71,11 @@ __device__ __forceinline__ unsigned p3_cvt_pk_bf16(float lo, float hi) {      //
 }
 
 // ---- producers ----------------------------------------------------------------------------------------------------
-// Wave pw moves rows 32 pw .. 32 pw + 31 of every chunk: 8 buffer loads of 4 rows x 256 B (lane = 16-byte piece c of row
-// rq), two chunks ahead in registers; split; 3 x 8 ds_write_b64.  The chunk's weights / run metadata go by LDS-DMA (one
+// Wave pw moves rows 4 pw .. 4 pw + 3 of EVERY 16-row tile of a chunk (load i <-> row tile i): 8 buffer loads of 4 rows x
+// 256 B (lane = 16-byte piece c of row rq), two chunks ahead in registers; split and 3 ds_write_b64 per USED row tile -- a
+// chunk at tile 224 holds 4.5 of its 8 row tiles on average, and with this dealing every wave skips the same unused ones
+// (their loads are still issued -- padding rows are out of range and cost no memory traffic -- so that the number of
+// operations in flight stays what the waits count).  The chunk's weights / run metadata go by LDS-DMA (one
 // 256-byte dma4 per wave and chunk).
 struct P3Rows {     // what one producer batch loads: set j % 3 holds chunk j
     f32x4 v[8];    // the wave's 32 rows of chunk j (lane: 16-byte piece c of row 4 i + rq)
@@ -123,7 +126,7 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     const unsigned rowb = c < a.din4 ? (unsigned)a.ldx * 4u : 0u;
     auto idx_ptr = [&](int k) {
         const int kk = k < nch ? k : nch - 1;
-        return a.slot_src + (size_t)(c0 + kk) * kP3CH + 32 * pw + (lane & 31);
+        return a.slot_src + (size_t)(c0 + kk) * kP3CH + 16 * ((lane & 31) >> 2) + 4 * pw + (lane & 3);      // lane 4 i + rq: row 16 i + 4 pw + rq
     };
     auto issue_loads = [&](P3Rows& r, int idxv) {
         int idx[8];
@@ -143,11 +146,12 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     int* meta_dst = (pw < 2 ? (int*)wring : dring) + 64 * half + lane;
     auto issue_meta = [&](P3Rows& r, int k) { p3_load_int(r.meta, meta_src + (size_t)(c0 + k) * kP3CH); };
     auto store_meta = [&](const P3Rows& r, int k) { meta_dst[(k & 1) * kP3CH] = r.meta; };
-    auto split_store = [&](const P3Rows& r, int k) {
+    auto split_store = [&](const P3Rows& r, int k, int nrt) {
         char* slot = ring + (k & 1) * kP3SlotBytes;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int row = 32 * pw + 4 * i + rq;
+            if (i >= nrt) break;                   // row tiles the chunk does not use
+            const int row = 16 * i + 4 * pw + rq;
             float x0 = r.v[i][0], x1 = r.v[i][1], x2 = r.v[i][2], x3 = r.v[i][3];
             if (RGCN_P3_ABL & 8) {
                 char* p8 = slot + row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + ((c & 1) << 3);
@@ -213,7 +217,9 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     issue_batch(r1, 1, i1);                        // + indices of chunk 3
     p3_wait_batch<10>(r0);                         // all but the youngest batch: rows of chunk 0, indices of chunk 2
     issue_batch(r2, 2, r0.idx);                    // + indices of chunk 4
-    split_store(r0, 0);
+    auto tiles_of = [&](int k) { return (ldc(a.chunk_cnt, c0 + (k < nch ? k : nch - 1)) + 15) >> 4; };
+    int nrt_next = tiles_of(1);                    // row tiles of chunk it + 1, fetched an iteration ahead (scalar load)
+    split_store(r0, 0, tiles_of(0));
     store_meta(r0, 0);
     wg_barrier();                                  // chunk 0 (and the accumulator init) visible
     // (batches are issued for chunks past the end too, from clamped addresses: the count of operations in flight stays what
@@ -229,8 +235,10 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
         if (it + 1 < nch) issue_batch(tgt, it + 3, src.idx);
         __builtin_amdgcn_sched_barrier(0);
         P3S(q2);
+        const int nrt_now = nrt_next;
+        nrt_next = tiles_of(it + 2);
         if (it + 1 < nch) {
-            split_store(src, it + 1);
+            split_store(src, it + 1, nrt_now);
             store_meta(src, it + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
