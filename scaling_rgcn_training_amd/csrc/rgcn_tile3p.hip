@@ -143,9 +143,10 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     };
     const int half = pw & 1;
     const int* meta_src = (pw < 2 ? (const int*)a.slot_w : a.slot_acc) + 64 * half + lane;
-    int* meta_dst = (pw < 2 ? (int*)wring : dring) + 64 * half + lane;
+    // the ring's metadata: [2][128] pairs {weight, run metadata} -- one 8-byte read per row tile for the consumers
+    int* meta_dst = (int*)wring + 2 * (64 * half + lane) + (pw < 2 ? 0 : 1);
     auto issue_meta = [&](P3Rows& r, int k) { p3_load_int(r.meta, meta_src + (size_t)(c0 + k) * kP3CH); };
-    auto store_meta = [&](const P3Rows& r, int k) { meta_dst[(k & 1) * kP3CH] = r.meta; };
+    auto store_meta = [&](const P3Rows& r, int k) { meta_dst[(k & 1) * 2 * kP3CH] = r.meta; };
     auto split_store = [&](const P3Rows& r, int k, int nrt) {
         char* slot = ring + (k & 1) * kP3SlotBytes;
 #pragma unroll
@@ -342,16 +343,16 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 xrow[s] = ring + buf * kP3SlotBytes + rowl * 128 + (((4 * s + kq) ^ ((rowl >> 1) & 7)) << 4);
-            const float* wb = wring + buf * kP3CH;
-            const int* db = dring + buf * kP3CH;
+            const int2* mb = (const int2*)wring + buf * kP3CH;          // {weight bits, run metadata} per slot
             struct Ops {
                 bf16x8 pl[3][2];    // [plane][k-step]: 8 bf16 of row rowl, k = 32 s + 8 kq + (0..7)
                 float w1;
                 int d1;
             };
             auto load_ops = [&](Ops& o, int t) {
-                o.w1 = wb[t * 16 + rowl];
-                o.d1 = db[t * 16 + rowl];
+                const int2 wd = mb[t * 16 + rowl];
+                o.w1 = __int_as_float(wd.x);
+                o.d1 = wd.y;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -437,8 +438,14 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
                     *(f32x4*)d = yv * o.w1 + oldv;
                     return;
                 }
-                const f32x4 w4 = *(const f32x4*)(wb + t * 16 + 4 * kq);
-                const i32x4 d4 = *(const i32x4*)(db + t * 16 + 4 * kq);
+                f32x4 w4;
+                i32x4 d4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int2 wd = mb[t * 16 + 4 * kq + i];
+                    w4[i] = __int_as_float(wd.x);
+                    d4[i] = wd.y;
+                }
                 f32x4 yv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
