@@ -9,6 +9,9 @@ n, e, r = 10_000_000, 100_000_000, 32
 dev = torch.device("cuda:0")
 ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, r, 64, 64, dev)
 tile, chunk = P.choose_layout(n, e, r, 64, 64)
+KF = int(os.environ.get("VT_FLAGS", 0))
+if KF & _lib.FLAG_SPLIT_PRODUCERS:
+    tile = min(tile, 224)
 plans = P.build_graph_plans_device(ei, et, n, r, tile, chunk=chunk, dw_tiles=False)
 del ei, et
 pkt = _lib.pack_weights(w, root, True)
@@ -28,7 +31,7 @@ def t(fn, reps=10):
     return ts[len(ts) // 2]
 
 def run_dx():
-    _lib.bwd_dx(pst, dg, 64, pkt, dx, 64)
+    _lib.bwd_dx(pst, dg, 64, pkt, dx, 64, None, KF)
 
 def run_root():
     _lib.bwd_dw_root(x, 64, dg, 64, dr, db)
