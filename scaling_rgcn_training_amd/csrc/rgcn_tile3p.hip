@@ -113,7 +113,18 @@ __device__ __forceinline__ void p3_wait_batch(P3Rows& r) {
 }
 
 __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, float* wring, int* dring, int c0, int nch,
-                                                 int lane, int pw) {
+                                                 int lane, int pw, int tile0) {
+    // c0 / nch: the chunks of ALL the tiles the workgroup walks, one sequence for the ring; where a chunk closes a tile the
+    // consumers store and reset the accumulator: the producers join one extra barrier there (equal barrier counts)
+    int tile_cur = tile0;
+    int tend = ldc(a.tile_ptr, tile0 + 1) - c0;
+    auto tile_boundary = [&](int it) {
+        if (it + 1 == tend && it + 1 < nch) {
+            ++tile_cur;
+            tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
+            wg_barrier();
+        }
+    };
     const int c = lane & 15, rq = lane >> 4;
     // raw buffer descriptor of x (stride 0, offen addressing, range check on num_records: rgcn_common.h make_rsrc)
     const unsigned long long xb = (unsigned long long)a.x;
@@ -245,6 +256,7 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
         __builtin_amdgcn_sched_barrier(0);
         P3S(q3);
         wg_barrier();
+        tile_boundary(it);
         P3S(q4);
         P3A(sp_wait, q0, q1); P3A(sp_issue, q1, q2); P3A(sp_split, q2, q3); P3A(sp_bar, q3, q4);
     };
@@ -274,10 +286,12 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // one tile per workgroup (walking several tiles per workgroup, as rgcn_tile_kernel does, measured no faster here)
-    const int tile = blockIdx.x;
-    const int c0 = ldc(a.tile_ptr, tile);
-    const int nch = ldc(a.tile_ptr, tile + 1) - c0;
+    // a workgroup walks `tiles_per_wg` consecutive tiles: one chunk sequence for the ring; between two tiles only the
+    // accumulator is stored and reset (the producers' two-iteration lead runs across the boundary)
+    const int tile0 = blockIdx.x * a.tiles_per_wg;
+    const int tile1 = min(tile0 + a.tiles_per_wg, a.n_tiles);
+    const int c0 = ldc(a.tile_ptr, tile0);
+    const int nch = ldc(a.tile_ptr, tile1) - c0;
 
     for (int i = tid; i < (a.tile + 1) * LDO; i += kP3Threads) {
         const int col = i % LDO;
@@ -314,6 +328,8 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
         };
         bool pending = rel_n1 != rel_cur;
         if (pending) prefetch_rel(rel_n1);
+        int tile_cur = tile0;
+        int tend = ldc(a.tile_ptr, tile0 + 1) - c0;     // first chunk (relative) of the next tile
         wg_barrier();
 #ifdef RGCN_P3_STAMPS
         unsigned long long sc_meta = 0, sc_comp = 0, sc_swap = 0, sc_bar = 0;
@@ -500,6 +516,15 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
             if (pending) prefetch_rel(rel_next2);
             P3S(t3);
             wg_barrier();
+            if (it + 1 == tend && it + 1 < nch) {
+                // this chunk closed a tile: the 256 consumer threads store it and reset the accumulator; the producers wait at
+                // the same extra barrier with the next tile's first chunks already in LDS / in flight
+                tile_epilogue<LDO, true>(a, out_lds, tile_cur, tid - 256, 256);
+                ++tile_cur;
+                tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the epilogue's memory operations here, once per tile
+                wg_barrier();
+            }
             P3S(t4);
             P3A(sc_meta, t0, t1); P3A(sc_comp, t1, t2); P3A(sc_swap, t2, t3); P3A(sc_bar, t3, t4);
         }
@@ -511,8 +536,8 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
 #endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the consumers is pending when the producer code follows
     }
-    if (wave < 4) p3_producer_loop(a, ring, wring, dring, c0, nch, lane, wave);
-    tile_epilogue<LDO, false>(a, out_lds, tile, tid, kP3Threads);
+    if (wave < 4) p3_producer_loop(a, ring, wring, dring, c0, nch, lane, wave, tile0);
+    tile_epilogue<LDO, false>(a, out_lds, tile1 - 1, tid, kP3Threads);
 }
 
 // bytes of dynamic LDS at tile size `tile`
@@ -536,7 +561,8 @@ int launch_tile3p(const TileArgs& a, int n_tiles, void* stream) {
         if (e != hipSuccess) return (int)e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(rgcn_tile3p_kernel, dim3(n_tiles), dim3(kP3Threads), lds, (hipStream_t)stream, a);
+    const int nwg = (n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    hipLaunchKernelGGL(rgcn_tile3p_kernel, dim3(nwg), dim3(kP3Threads), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
