@@ -527,3 +527,48 @@ def test_split_producers_through_the_module(dev):
         outs.append([t.detach().cpu().numpy() for t in (out, xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad, act)])
     for a, b in zip(outs[1], outs[0]):
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(b).max())))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_split_producers_random_shapes_against_exact_fp32(dev, seed):
+    """Producer-split kernel vs the exact-fp32 kernel on the SAME plan for random graphs: node counts that leave a partial last
+    tile, tiles of 16..224 nodes, 1..40 relations, widths 33..64, hubs (run-sum path), relations without edges; and one graph
+    of more than 4,096 tiles, where its workgroups walk several tiles (the ring's chunk sequence crosses tile boundaries)."""
+    from scaling_rgcn_training_amd import _lib, plan as P
+    from scaling_rgcn_training_amd.conv import _rows16, _round4
+    g = torch.Generator().manual_seed(100 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    if seed == 5:
+        n, e, r, tile = 1_000_003, 3_000_000, 6, 224          # 4,465 tiles: persistent workgroups
+    else:
+        n, r, tile = ri(50, 30000), ri(1, 40), 16 * ri(1, 14)
+        e = ri(n, 40 * n)
+    din, dout = ri(33, 64), ri(33, 64)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    if seed % 2 == 0:
+        m = torch.rand(e, generator=g) < 0.2
+        dst[m] = torch.randint(0, 8, (int(m.sum()),), generator=g)
+    et = torch.randint(0, max(1, r - 1), (e,), generator=g)          # the last relation stays empty when r > 1
+    ei = torch.stack([src, dst]).to(dev)
+    plans = P.build_graph_plans_device(ei, et.to(dev), n, r, tile, chunk=128, dw_tiles=False)
+    x = _rows16(torch.randn(n, din, generator=g).to(dev), din)
+    dg = _rows16(torch.randn(n, dout, generator=g).to(dev), dout)
+    w = (torch.randn(r, din, dout, generator=g) * 0.2).to(dev)
+    root = (torch.randn(din, dout, generator=g) * 0.2).to(dev)
+    bias = torch.randn(dout, generator=g).to(dev)
+    F = _lib.FLAG_SPLIT_PRODUCERS
+    o = [torch.full((n, _round4(dout)), float("nan"), device=dev) for _ in range(2)]
+    pk = _lib.pack_weights(w, root, False)
+    for k, fl in enumerate((0, F)):
+        _lib.fwd(_lib.plan_struct(plans.fwd), x, din, pk, bias, o[k], dout, _lib.ACT_RELU if seed % 3 == 0 else 0, fl)
+    d = [torch.full((n, _round4(din)), float("nan"), device=dev) for _ in range(2)]
+    pkt = _lib.pack_weights(w, root, True)
+    for k, fl in enumerate((0, F)):
+        _lib.bwd_dx(_lib.plan_struct(plans.bwd), dg, dout, pkt, d[k], din, x if seed % 2 else None, fl)
+    torch.cuda.synchronize()
+    for a, b, width, what in ((o[1], o[0], dout, "forward"), (d[1], d[0], din, "dX")):
+        a, b = a[:, :width], b[:, :width]
+        assert not torch.isnan(a).any(), what
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (what, n, e, r, tile, din, dout, float((a - b).abs().max()), scale)

@@ -10,6 +10,7 @@ cd "$out/obj_$name"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c "$ROOT/scaling_rgcn_training_amd/csrc/rgcn_kernels.hip" -o k.o &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c "$ROOT/scaling_rgcn_training_amd/csrc/rgcn_dw_root.hip" -o r.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$ROOT/scaling_rgcn_training_amd/csrc/rgcn_plan.hip" -o p.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c "$ROOT/scaling_rgcn_training_amd/csrc/rgcn_tile3p.hip" -o t.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared k.o r.o p.o -o "$out/$name.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared k.o r.o p.o t.o -o "$out/$name.so"
 echo "built $out/$name.so"
