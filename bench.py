@@ -406,7 +406,14 @@ def main():
     if world == 1 and (n, e, r, d) == HEADLINE and not args.no_ladder and not args.split_precision:
         main_mode = conv.split_producers
         try:
+            with torch.no_grad():
+                out_main = conv(x, ei, et)
             conv.split_producers = not main_mode
+            with torch.no_grad():
+                out_alt = conv(x, ei, et)
+            fwd_diff = float((out_main - out_alt).abs().max())
+            fwd_max = float(out_alt.abs().max())
+            del out_main, out_alt
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
@@ -420,7 +427,9 @@ def main():
             alt = {"what": ("forward / dX on rgcn_tile3p_kernel (operand split by the producer waves, bf16 x 3 MFMAs, fp32-equivalent)"
                             if conv.split_producers else
                             "forward / dX on rgcn_tile_kernel (exact-fp32 MFMA; RGCNConv.split_producers = False / RGCN_SPLIT_PRODUCERS=0)"),
-                   "ms_per_step_median": ams, "steps": 15, "edges_per_s": e / (ams * 1e-3)}
+                   "ms_per_step_median": ams, "steps": 15, "edges_per_s": e / (ams * 1e-3),
+                   # the two kernels' forward outputs on this very input, element by element (fp32-equivalence in the record)
+                   "forward_max_abs_diff_between_kernels": fwd_diff, "forward_max_abs": fwd_max}
             log(f"alt ({'producer-split bf16x3' if conv.split_producers else 'exact-fp32'} forward / dX): {ams:.2f} ms/step")
         except Exception as err:      # the secondary leg must never take the headline record down
             log(f"alt leg skipped: {err!r}")
