@@ -50,7 +50,9 @@ enum rgcn_act { RGCN_ACT_NONE = 0, RGCN_ACT_RELU = 1, RGCN_ACT_SIGMOID = 2 };
 #define RGCN_FLAG_DW_ROOT_ONLY 16u   /* rgcn_bwd_dw: d_root and d_bias only (the relations went to rgcn_bwd_dw_tiles) */
 #define RGCN_FLAG_SPLIT_PRODUCERS 32u /* rgcn_fwd / rgcn_bwd_dx: the bf16 x 3 kernel whose PRODUCER waves split the gathered rows
                                        * (fp32-equivalent: 24 significant bits on both operands, six bf16 products): 64 x 64 layers,
-                                       * 128-slot chunks, layout 0, tile <= 224; other shapes take the exact-fp32 kernel */
+                                       * 128-slot chunks, layout 0, tile <= 224; other shapes take the exact-fp32 kernel.
+                                       * rgcn_bwd_dw_tiles: the same walk with both operands split into three bf16 pieces in registers
+                                       * (six bf16 products, fp32 accumulation; same fp32-equivalence) */
 #define RGCN_FLAG_EXACT_FP32 8u     /* rgcn_fwd / rgcn_bwd_dx: the exact-fp32 MFMA kernel also where the split-precision
                                      * (bf16 x 3, six products: fp32-equivalent) kernel applies: 64 x 64 on layout-1 plans */
 

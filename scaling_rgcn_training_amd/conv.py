@@ -430,7 +430,7 @@ class RGCNConv(nn.Module):
         flags = self.kernel_flags
         first = plans.fwd if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
         if first is not None and self._use_split_producers(first.chunk) and first.layout == 0:
-            flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx only; the library falls back where it does not fit
+            flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles; the library falls back where it does not fit
         return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist,
                                   _activation, _input_relu, _grad_premasked and _activation == "relu", flags)
 

@@ -871,6 +871,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
 // 2 accumulator read-modify-writes of 16 bytes per lane.  Row tiles with a repeated destination take the Y
 // orientation (operands swapped) and the same run-sum product P.Y as rgcn_tile_kernel, in exact fp32.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPack3FragsPerRel = 2 * 3 * 2 * 2;        // [column half c][plane][column tile ct][k-step s]
 constexpr size_t kPack3FloatsPerRel = (size_t)kPack3FragsPerRel * 64 * 4;   // 64 lanes x 16 bytes per fragment
@@ -2062,6 +2063,9 @@ __global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) 
 // Traffic: x gathers E * 4 * in + four sweeps of g (4 N * 4 * out) + indices = 37 GB instead of 55; one barrier per tile.
 // The root relation and the bias gradient stay with rgcn_dw_direct_kernel (RGCN_FLAG_DW_ROOT_ONLY): their x rows are
 // the tile's own.
+#ifndef RGCN_DW_XCD_MAP
+#define RGCN_DW_XCD_MAP 1
+#endif
 constexpr int kDwTileT = 304;                    // gradient rows per LDS buffer = tile size of the plan this kernel walks
 constexpr int kDwTileWalkers = 64;               // tile ranges; x 4 relation quarters = 256 workgroups, one per CU
 constexpr int kDwTileMaxRel = 32;
@@ -2081,13 +2085,25 @@ struct DwTileArgs {
     int ldx, ldg, dout4, n_tiles, n_owned, num_rel, walkers;
 };
 
+// SPLIT: the same walk with the contraction as a bf16 x 3 split of BOTH fp32 operands (x row values and weight * gradient
+// values -> three bf16 pieces each, split in registers by the wave that uses them; six v_mfma_f32_16x16x32_bf16 products
+// hh, hm, mh, hl, lh, mm, fp32 accumulation: 24 significant bits on both sides, as rgcn_tile3p_kernel).  A 64-slot unit is two
+// 32-row k-steps of that MFMA = the two halves of the register pipeline, with slot 32 h + 4 s + kq as k index 8 kq + s on both
+// operands (a sum over k does not care which slot sits where, only that A and B agree).  96 MFMAs of 16 cycles per half
+// against 256 of 32: the exact-fp32 form of this kernel is bound by the fp32 MFMA rate.
+template <bool SPLIT>
 __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a) {
     constexpr int T = kDwTileT, NP = 64, HS = 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][T][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if RGCN_DW_XCD_MAP
+    // the four relation quarters of a tile range on ONE XCD (workgroup b runs on XCD b % 8): they stage the same gradient rows
+    const int quarter = (blockIdx.x >> 3) & 3, p = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3);
+#else
     const int quarter = blockIdx.x & 3, p = blockIdx.x >> 2;
+#endif
     const int rel = 8 * quarter + wave;
     const bool have = rel < a.num_rel;
     const int t0 = (int)((long)p * a.n_tiles / a.walkers), t1 = (int)((long)(p + 1) * a.n_tiles / a.walkers);
@@ -2167,6 +2183,57 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
         }
     };
 
+    // v0, v1 -> three packed bf16 pairs (low half = v0), round-to-nearest pieces: v = h + m + l to 24 bits
+    auto split_pair = [](float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
+        v0 -= __uint_as_float(h << 16);
+        v1 -= __uint_as_float(h & 0xFFFF0000u);
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m) : "v"(v0), "v"(v1));
+        v0 -= __uint_as_float(m << 16);
+        v1 -= __uint_as_float(m & 0xFFFF0000u);
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(v0), "v"(v1));
+    };
+    // half a unit as ONE 32-row k-step (a half with no valid slot is skipped; padding slots inside one have weight 0)
+    auto compute_half3 = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {
+        if (2 * h >= ngrp) return;
+        const unsigned loc = (unsigned)(ix.g - tile_row0);
+        const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));
+        float wv[HS];
+        f32x4 g4[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            wv[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), __builtin_bit_cast(int, ix.w)));
+            const int o = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), goff);
+            g4[s] = *(const f32x4*)((const char*)gbuf + o + colb);
+        }
+        u32x4 ap[3][4];      // [piece][ia]: 8 bf16 = k index 8 kq + 0..7 of input channel 4 ml + ia
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                unsigned h_, m_, l_;
+                split_pair(a4[2 * jp][ia], a4[2 * jp + 1][ia], h_, m_, l_);
+                ap[0][ia][jp] = h_; ap[1][ia][jp] = m_; ap[2][ia][jp] = l_;
+            }
+        constexpr int pa[6] = {2, 1, 1, 0, 0, 0}, pb[6] = {0, 1, 0, 2, 1, 0};      // small products first
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            u32x4 bp[3];
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                unsigned h_, m_, l_;
+                split_pair(g4[2 * jp][jb] * wv[2 * jp], g4[2 * jp + 1][jb] * wv[2 * jp + 1], h_, m_, l_);
+                bp[0][jp] = h_; bp[1][jp] = m_; bp[2][jp] = l_;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+                    acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[pa[q]][ia]),
+                                                                          __builtin_bit_cast(bf16x8, bp[pb[q]]), acc[ia][jb], 0, 0, 0);
+        }
+    };
+
     dma_tile(t0, 0);
     int k = 0;
     int uid_cur = unit_of(0), uid_nxt = unit_of(1), uid_nn = unit_of(2);
@@ -2187,12 +2254,14 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             const int ngrp = (cnt_cur + 15) >> 4, nks = (cnt_cur + 3) >> 2;
             issue_half(s1, ix_cur, 1);
             __builtin_amdgcn_sched_barrier(0);
-            compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
+            if constexpr (SPLIT) compute_half3(s0, ix_cur, 0, ngrp, gbuf, t * T);
+            else compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             const Idx ix_nn = load_idx(uid_nn);
             issue_half(s0, ix_nxt, 0);
             __builtin_amdgcn_sched_barrier(0);
-            compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
+            if constexpr (SPLIT) compute_half3(s1, ix_cur, 1, ngrp, gbuf, t * T);
+            else compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             ++k;
             ix_cur = ix_nxt;
@@ -2782,12 +2851,14 @@ extern "C" int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_pt
     a.walkers = kDwTileWalkers;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float) * 2 * kDwTileT * 64;
-    hipError_t e = allow_full_lds<rgcn_dw_tile_kernel>();
+    const bool split = (flags & RGCN_FLAG_SPLIT_PRODUCERS) != 0;
+    hipError_t e = split ? allow_full_lds<rgcn_dw_tile_kernel<true>>() : allow_full_lds<rgcn_dw_tile_kernel<false>>();
     if (e != hipSuccess) return (int)e;
     // walkers without tiles leave their slabs untouched: clear what the reduction reads
     e = hipMemsetAsync(workspace, 0, rgcn_bwd_dw_tiles_workspace_bytes(plan->num_relations), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(rgcn_dw_tile_kernel, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+    if (split) hipLaunchKernelGGL(rgcn_dw_tile_kernel<true>, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(rgcn_dw_tile_kernel<false>, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
     if ((st = (int)hipGetLastError()) != 0) return st;
     hipLaunchKernelGGL(rgcn_dw_tile_reduce_kernel, dim3(plan->num_relations, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs,
                        kDwTileWalkers, plan->num_relations, din, dout, d_weight);

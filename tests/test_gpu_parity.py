@@ -401,8 +401,9 @@ def test_split_precision_kernel_matches_oracle(dev, n, e, r, tile, skew):
     assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "bf16x3"])
 @pytest.mark.parametrize("n,e,r,skew", [(5000, 90000, 7, False), (20000, 600000, 32, False), (3000, 200000, 3, True), (700, 5000, 32, False)])
-def test_dw_tile_major_kernel(dev, n, e, r, skew):
+def test_dw_tile_major_kernel(dev, n, e, r, skew, split):
     """rgcn_bwd_dw_tiles (tile-major d_weight: one relation per wave, gradient rows staged in LDS) + the root-only walk of
     rgcn_bwd_dw against the oracle, and against the relation-major kernels on the same inputs."""
     from scaling_rgcn_training_amd import _lib, plan as P
@@ -425,7 +426,8 @@ def test_dw_tile_major_kernel(dev, n, e, r, skew):
     assert torch.equal(plans.dw_walk, P.dw_walk_table(plans.dw, walkers))
     xd, gd = x.to(dev), dg.to(dev)
     dw = torch.full((r, din, dout), float("nan"), device=dev)
-    _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, xd, din, gd, dout, dw)
+    # split: the same walk with both operands cut into three bf16 pieces by the wave that uses them (fp32-equivalent; same bounds)
+    _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, xd, din, gd, dout, dw, _lib.FLAG_SPLIT_PRODUCERS if split else 0)
     dr = torch.full((din, dout), float("nan"), device=dev)
     db = torch.full((dout,), float("nan"), device=dev)
     _lib.bwd_dw(_lib.plan_struct(plans.fwd), xd, din, gd, dout, None, dr, db, _lib.FLAG_DW_ROOT_ONLY)

@@ -50,7 +50,7 @@ def child():
     if "dw" in which:
         dw, dr, db = torch.empty_like(w), torch.empty_like(root), torch.empty(64, device=dev)
         psd, psf = _lib.plan_struct(plans.dw), _lib.plan_struct(plans.fwd)
-        m, lo = t(lambda: _lib.bwd_dw_tiles(psd, plans.dw_walk, x, 64, dg, 64, dw))
+        m, lo = t(lambda: _lib.bwd_dw_tiles(psd, plans.dw_walk, x, 64, dg, 64, dw, kflags))
         print("  dw tiles   %.3f ms (min %.3f)  checksum %s" % (m, lo, cs(dw)), flush=True)
         m, lo = t(lambda: _lib.bwd_dw(psf, x, 64, dg, 64, None, dr, db, _lib.FLAG_DW_ROOT_ONLY))
         print("  dw root    %.3f ms (min %.3f)  checksum %s %s" % (m, lo, cs(dr), cs(db)), flush=True)
