@@ -26,7 +26,8 @@ The JSON line also carries
                  DESIGN.md; the binding roof is the one that needs more time at its peak -- HBM for the default
                  forward / dX kernel, whose contraction runs on bf16 MFMAs over 3-way split fp32 operands; the fp32
                  MFMA peak for the exact-fp32 kernel (--no-split-producers), with the HBM figures beside it)
-  alt_forward_kernel  the same step with the OTHER forward / dX kernel, timed on the same box right after the main run
+  alt_forward_kernel  the same step with the OTHER kernels (exact-fp32 forward / dX / d_weight when the bf16x3 split forms ran,
+                 and vice versa), timed on the same box right after the main run, + the element-wise differences of their results
   roofline_step  the whole step against HBM: algorithmic bytes of fwd + bwd (92.1 GB at the headline config) / ms_per_step
                  -- the number north_star's ">= 40 % of HBM roofline" refers to
   ladder         GPU edges/s on the smaller rungs of SURVEY.md 8d ((100k, 1M), (1M, 10M), AIFB shape)
@@ -414,6 +415,13 @@ def main():
             fwd_diff = float((out_main - out_alt).abs().max())
             fwd_max = float(out_alt.abs().max())
             del out_main, out_alt
+            dw_diff = dw_max = None
+            if psd is not None:      # d_weight by both forms of the tile-major kernel on the same operands
+                dw_b = torch.empty_like(dw)
+                _lib.bwd_dw_tiles(psd, plans.dw_walk, xd, d, dg, d, dw, conv.kernel_flags | _lib.FLAG_SPLIT_PRODUCERS)
+                _lib.bwd_dw_tiles(psd, plans.dw_walk, xd, d, dg, d, dw_b, conv.kernel_flags)
+                dw_diff, dw_max = float((dw - dw_b).abs().max()), float(dw_b.abs().max())
+                del dw_b
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
@@ -426,11 +434,12 @@ def main():
             ams = statistics.median(a.elapsed_time(b) for a, b in aevs)
             alt = {"what": ("forward / dX on rgcn_tile3p_kernel (operand split by the producer waves, bf16 x 3 MFMAs, fp32-equivalent)"
                             if conv.split_producers else
-                            "forward / dX on rgcn_tile_kernel (exact-fp32 MFMA; RGCNConv.split_producers = False / RGCN_SPLIT_PRODUCERS=0)"),
+                            "forward / dX on rgcn_tile_kernel and d_weight on rgcn_dw_tile_kernel<false> (exact-fp32 MFMA everywhere; RGCNConv.split_producers = False / RGCN_SPLIT_PRODUCERS=0)"),
                    "ms_per_step_median": ams, "steps": 15, "edges_per_s": e / (ams * 1e-3),
                    # the two kernels' forward outputs on this very input, element by element (fp32-equivalence in the record)
-                   "forward_max_abs_diff_between_kernels": fwd_diff, "forward_max_abs": fwd_max}
-            log(f"alt ({'producer-split bf16x3' if conv.split_producers else 'exact-fp32'} forward / dX): {ams:.2f} ms/step")
+                   "forward_max_abs_diff_between_kernels": fwd_diff, "forward_max_abs": fwd_max,
+                   "d_weight_max_abs_diff_between_kernels": dw_diff, "d_weight_max_abs": dw_max}
+            log(f"alt ({'bf16x3 split' if conv.split_producers else 'exact-fp32'} forward / dX / dW): {ams:.2f} ms/step")
         except Exception as err:      # the secondary leg must never take the headline record down
             log(f"alt leg skipped: {err!r}")
         finally:

@@ -2063,6 +2063,12 @@ __global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) 
 // Traffic: x gathers E * 4 * in + four sweeps of g (4 N * 4 * out) + indices = 37 GB instead of 55; one barrier per tile.
 // The root relation and the bias gradient stay with rgcn_dw_direct_kernel (RGCN_FLAG_DW_ROOT_ONLY): their x rows are
 // the tile's own.
+#ifndef RGCN_DW_ABL_NOBARRIER
+#define RGCN_DW_ABL_NOBARRIER 0
+#endif
+#ifndef RGCN_DW_TRUNC
+#define RGCN_DW_TRUNC 0
+#endif
 #ifndef RGCN_DW_XCD_MAP
 #define RGCN_DW_XCD_MAP 1
 #endif
@@ -2185,6 +2191,16 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
 
     // v0, v1 -> three packed bf16 pairs (low half = v0), round-to-nearest pieces: v = h + m + l to 24 bits
     auto split_pair = [](float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+#if RGCN_DW_TRUNC      // pieces by truncation (v_perm_b32 packs two upper halves; exact as well): measured, see DESIGN.md 4.3
+        auto pk = [](float lo, float hi) { return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u); };
+        auto top = [](float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); };
+        h = pk(v0, v1);
+        v0 -= top(v0); v1 -= top(v1);
+        m = pk(v0, v1);
+        v0 -= top(v0); v1 -= top(v1);
+        l = pk(v0, v1);
+        return;
+#endif
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
         v0 -= __uint_as_float(h << 16);
         v1 -= __uint_as_float(h & 0xFFFF0000u);
@@ -2242,16 +2258,24 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     Idx ix_cur = load_idx(uid_cur), ix_nxt = load_idx(uid_nxt);
     f32x4 s0[HS], s1[HS];
     if (nun > 0) issue_half(s0, ix_cur, 0);
+    bool walked = nun > 0;      // at least 11 vector-memory operations were issued after the pending tile's DMAs
     for (int t = t0; t < t1; ++t) {
-        // The DMAs of tile t were issued a tile ago (or in the prologue), before every x load of the units walked since; at
-        // most 11 younger operations are in flight at a unit boundary (8 row loads + 3 index loads of the unit after next).
-        asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        // The DMAs of tile t were issued a tile ago (or in the prologue).  If the wave has walked a unit since (or issued the
+        // prologue's loads), more than 11 younger operations exist and at most 11 are in flight at a unit boundary (8 row loads
+        // + 3 index loads of the unit after next): a counted wait retires the DMAs and leaves the prefetches alone.  A wave
+        // without units in between (an empty relation) has nothing younger to count: it waits for everything.
+        if (walked) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !RGCN_DW_ABL_NOBARRIER      // (timing only: the waves of a workgroup run free -- what the tile lockstep costs)
         wg_barrier();          // tile t landed for every wave; every wave is done with the buffer tile t + 1 goes to
+#endif
         const int b = (t - t0) & 1;
         if (t + 1 < t1) dma_tile(t + 1, b ^ 1);
+        walked = false;
         const float* gbuf = lds + b * T * NP;
         while (k < nun && tile_cur == t) {
             const int ngrp = (cnt_cur + 15) >> 4, nks = (cnt_cur + 3) >> 2;
+            walked = true;
             issue_half(s1, ix_cur, 1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SPLIT) compute_half3(s0, ix_cur, 0, ngrp, gbuf, t * T);
