@@ -531,6 +531,77 @@ def test_split_producers_through_the_module(dev):
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(b).max())))
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "bf16x3"])
+def test_tile_major_dw_through_the_module(dev, monkeypatch, split):
+    """The backward the headline configuration takes -- d_weight by ``rgcn_bwd_dw_tiles`` (both forms), d_root / d_bias by the
+    streaming kernel on the side stream beside dX, one flat gradient buffer -- forced onto a graph the oracle finishes in
+    seconds (the module takes this path from 4M edges / 262,144 nodes on), all four gradients against the float64 oracle."""
+    from scaling_rgcn_training_amd import conv as C
+    monkeypatch.setattr(C, "DW_TILES_MIN_EDGES", 1)
+    monkeypatch.setattr(C, "_SIDE_STREAM_MIN_ROWS", 1)
+    n, e, r = 20000, 500000, 32
+    ei, et = O.synthetic_graph(n, e, r, seed=12)
+    et = et.clamp(max=r - 2)                      # dead last relation: its wave walks no unit at all
+    w, root, bias = O.synthetic_params(r, 64, 64, seed=5)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, 64, generator=g)
+    dg = torch.randn(n, 64, generator=g)
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    conv = C.RGCNConv(64, 64, r).to(dev)
+    conv.split_producers = split
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.root.copy_(root)
+        conv.bias.copy_(bias)
+    eid, etd = ei.to(dev), et.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, eid, etd)
+    plans = conv._plans(xd, eid, etd)
+    assert plans.dw is not None and plans.dw.tile == 304            # the tile-major plan exists: backward takes that path
+    out.backward(dg.to(dev))
+    torch.cuda.synchronize()
+    c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
+    _, g32 = cpu32_reference(x, ei, et, w, root, bias, dg)
+    assert_close(out.detach().cpu().numpy(), ref, c_out, f"module out [{split}]")
+    assert_close(xd.grad.cpu().numpy(), gr["x"], c["x"], f"module d_x [{split}]", cpu32=g32["x"])
+    assert_close(conv.weight.grad.cpu().numpy(), gr["weight"], c["weight"], f"module d_weight (tile-major) [{split}]", cpu32=g32["weight"], cpu_factor=4.0)
+    assert_close(conv.root.grad.cpu().numpy(), gr["root"], c["root"], f"module d_root (side stream) [{split}]", cpu32=g32["root"])
+    assert_close(conv.bias.grad.cpu().numpy(), gr["bias"], c["bias"], f"module d_bias (side stream) [{split}]", cpu32=g32["bias"])
+    assert torch.all(conv.weight.grad[r - 1] == 0)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_dw_tile_major_split_random_shapes_against_exact_fp32(dev, seed):
+    """The bf16 x 3 form of the tile-major d_weight kernel vs its exact-fp32 form on the SAME plan: random node counts (partial
+    last tile, fewer tiles than walkers), 1..32 relations with an empty one, widths 33..64, hubs, strided operand rows."""
+    from scaling_rgcn_training_amd import _lib, plan as P
+    from scaling_rgcn_training_amd.conv import _rows16
+    g = torch.Generator().manual_seed(500 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    n, r = (ri(50, 3000) if seed % 2 else ri(3000, 60000)), ri(1, 32)
+    e = ri(n, 30 * n)
+    din, dout = ri(33, 64), ri(33, 64)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    if seed % 2 == 0:
+        m = torch.rand(e, generator=g) < 0.2
+        dst[m] = torch.randint(0, 8, (int(m.sum()),), generator=g)
+    et = torch.randint(0, max(1, r - 1), (e,), generator=g)
+    plans = P.build_graph_plans_device(torch.stack([src, dst]).to(dev), et.to(dev), n, r, 128, dw_tiles=True)
+    x = _rows16(torch.randn(n, din, generator=g).to(dev), din)
+    dg = _rows16(torch.randn(n, dout, generator=g).to(dev), dout)
+    res = []
+    for fl in (0, _lib.FLAG_SPLIT_PRODUCERS):
+        dw = torch.full((r, din, dout), float("nan"), device=dev)
+        _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, x, din, dg, dout, dw, fl)
+        res.append(dw.cpu().numpy())
+    scale = max(1.0, float(np.abs(res[0]).max()))
+    assert np.isfinite(res[1]).all()
+    np.testing.assert_allclose(res[1], res[0], rtol=0, atol=2e-5 * scale)
+    if r > 1:
+        assert not res[1][r - 1].any()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_split_producers_random_shapes_against_exact_fp32(dev, seed):
     """Producer-split kernel vs the exact-fp32 kernel on the SAME plan for random graphs: node counts that leave a partial last
