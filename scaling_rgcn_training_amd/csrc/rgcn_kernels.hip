@@ -2069,6 +2069,9 @@ __global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) 
 #ifndef RGCN_DW_TRUNC
 #define RGCN_DW_TRUNC 0
 #endif
+#ifndef RGCN_DW_ABL
+#define RGCN_DW_ABL 0      // timing-only ablations of rgcn_dw_tile_kernel<true>: 1 cached gathers, 2 no MFMAs, 4 no split arithmetic
+#endif
 #ifndef RGCN_DW_XCD_MAP
 #define RGCN_DW_XCD_MAP 1
 #endif
@@ -2151,6 +2154,9 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
         int ih[HS];
 #pragma unroll
         for (int s = 0; s < HS; ++s) ih[s] = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), ix.h);
+        if (RGCN_DW_ABL & 1)       // (timing only: every gather hits rows 0..63 -- no HBM traffic for x)
+#pragma unroll
+            for (int s = 0; s < HS; ++s) ih[s] &= 63;
 #pragma unroll
         for (int s = 0; s < HS; ++s)
             a4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)ih[s], rbx) + colb), 0, 0));
@@ -2191,6 +2197,12 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
 
     // v0, v1 -> three packed bf16 pairs (low half = v0), round-to-nearest pieces: v = h + m + l to 24 bits
     auto split_pair = [](float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+        if (RGCN_DW_ABL & 4) {      // (timing only: no split arithmetic)
+            h = __float_as_uint(v0);
+            m = __float_as_uint(v1);
+            l = h ^ m;
+            return;
+        }
 #if RGCN_DW_TRUNC      // pieces by truncation (v_perm_b32 packs two upper halves; exact as well): measured, see DESIGN.md 4.3
         auto pk = [](float lo, float hi) { return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u); };
         auto top = [](float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); };
@@ -2240,6 +2252,12 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
                 unsigned h_, m_, l_;
                 split_pair(g4[2 * jp][jb] * wv[2 * jp], g4[2 * jp + 1][jb] * wv[2 * jp + 1], h_, m_, l_);
                 bp[0][jp] = h_; bp[1][jp] = m_; bp[2][jp] = l_;
+            }
+            if (RGCN_DW_ABL & 2) {      // (timing only: no MFMAs; the pieces stay alive)
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+                    asm volatile("" ::"v"(ap[0][ia]), "v"(ap[1][ia]), "v"(ap[2][ia]), "v"(bp[0]), "v"(bp[1]), "v"(bp[2]));
+                continue;
             }
 #pragma unroll
             for (int q = 0; q < 6; ++q)
