@@ -2072,6 +2072,9 @@ __global__ void __launch_bounds__(256, 2) rgcn_dw_direct_kernel(const DwArgs a) 
 #ifndef RGCN_DW_ABL
 #define RGCN_DW_ABL 0      // timing-only ablations of rgcn_dw_tile_kernel<true>: 1 cached gathers, 2 no MFMAs, 4 no split arithmetic
 #endif
+#ifndef RGCN_DW_VECTOR_WALK
+#define RGCN_DW_VECTOR_WALK 0
+#endif
 #ifndef RGCN_DW_XCD_MAP
 #define RGCN_DW_XCD_MAP 1
 #endif
@@ -2268,21 +2271,37 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
         }
     };
 
+    // The halves are computed under conditions (a half without valid slots is skipped), and loads whose uses all sit in later
+    // blocks get SUNK there by the optimiser -- issued right in front of their first use, their whole latency exposed (that is
+    // where the second half's eight row loads of every unit were until this was found: the ISA showed them behind half 0's
+    // MFMAs, not at the top of the iteration; sched_barrier only binds the scheduler inside a block).  A compiler-level memory
+    // clobber after each batch keeps the loads where issue_half puts them: a read cannot be moved across it.
+    auto pin_loads = [] { asm volatile("" ::: "memory"); };
     dma_tile(t0, 0);
     int k = 0;
     int uid_cur = unit_of(0), uid_nxt = unit_of(1), uid_nn = unit_of(2);
     int cnt_cur = ldc(a.chunk_cnt, uid_cur), tile_cur = nun > 0 ? ldc(a.chunk_tile, uid_cur) : t1;
     int cnt_nxt = ldc(a.chunk_cnt, uid_nxt), tile_nxt = nun > 1 ? ldc(a.chunk_tile, uid_nxt) : t1;
+#if RGCN_DW_VECTOR_WALK
+    // Inside the walk the three per-unit words (unit id, slot count, tile) come by VECTOR loads of a uniform address: scalar
+    // loads return out of order, so the first LDS operation of the next unit -- its wait is lgkmcnt(0) -- would wait for the
+    // scalar loads issued a few instructions earlier, a full L2 round trip per unit; vector loads retire in order and are
+    // waited for by count, a whole unit after they were issued.
+    const __amdgpu_buffer_rsrc_t r_ord = make_rsrc(a.rel_order, 0xFFFFFFFCu), r_cnt = make_rsrc(a.chunk_cnt, 0xFFFFFFFCu),
+                                 r_til = make_rsrc(a.chunk_tile, 0xFFFFFFFCu);
+    auto ldv = [](__amdgpu_buffer_rsrc_t r, int idx) { return __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0); };
+#endif
     Idx ix_cur = load_idx(uid_cur), ix_nxt = load_idx(uid_nxt);
     f32x4 s0[HS], s1[HS];
     if (nun > 0) issue_half(s0, ix_cur, 0);
-    bool walked = nun > 0;      // at least 11 vector-memory operations were issued after the pending tile's DMAs
+    constexpr int kInFlight = RGCN_DW_VECTOR_WALK ? 14 : 11;      // 8 row loads + 3 index loads (+ 3 walk words)
+    bool walked = nun > 0;      // at least kInFlight vector-memory operations were issued after the pending tile's DMAs
     for (int t = t0; t < t1; ++t) {
         // The DMAs of tile t were issued a tile ago (or in the prologue).  If the wave has walked a unit since (or issued the
-        // prologue's loads), more than 11 younger operations exist and at most 11 are in flight at a unit boundary (8 row loads
-        // + 3 index loads of the unit after next): a counted wait retires the DMAs and leaves the prefetches alone.  A wave
+        // prologue's loads), more than kInFlight younger operations exist and at most kInFlight are in flight at a unit boundary (8 row
+        // loads + 3 index loads of the unit after next + the walk words): a counted wait retires the DMAs and leaves the prefetches alone.  A wave
         // without units in between (an empty relation) has nothing younger to count: it waits for everything.
-        if (walked) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        if (walked) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if !RGCN_DW_ABL_NOBARRIER      // (timing only: the waves of a workgroup run free -- what the tile lockstep costs)
         wg_barrier();          // tile t landed for every wave; every wave is done with the buffer tile t + 1 goes to
@@ -2295,12 +2314,14 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             const int ngrp = (cnt_cur + 15) >> 4, nks = (cnt_cur + 3) >> 2;
             walked = true;
             issue_half(s1, ix_cur, 1);
+            pin_loads();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SPLIT) compute_half3(s0, ix_cur, 0, ngrp, gbuf, t * T);
             else compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             const Idx ix_nn = load_idx(uid_nn);
             issue_half(s0, ix_nxt, 0);
+            pin_loads();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SPLIT) compute_half3(s1, ix_cur, 1, ngrp, gbuf, t * T);
             else compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
@@ -2310,11 +2331,19 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             ix_nxt = ix_nn;
             uid_cur = uid_nxt;
             uid_nxt = uid_nn;
+#if RGCN_DW_VECTOR_WALK
+            uid_nn = ldv(r_ord, i0 + (k + 2 < nun ? k + 2 : nun - 1));
+            cnt_cur = __builtin_amdgcn_readfirstlane(cnt_nxt);
+            tile_cur = k < nun ? __builtin_amdgcn_readfirstlane(tile_nxt) : t1;
+            cnt_nxt = ldv(r_cnt, uid_nxt);
+            tile_nxt = ldv(r_til, uid_nxt);       // (a clamped unit's tile is never looked at: tile_cur = t1 past the end)
+#else
             uid_nn = unit_of(k + 2);
             cnt_cur = cnt_nxt;
             tile_cur = k < nun ? tile_nxt : t1;
             cnt_nxt = ldc(a.chunk_cnt, uid_nxt);
             tile_nxt = k + 1 < nun ? ldc(a.chunk_tile, uid_nxt) : t1;
+#endif
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
