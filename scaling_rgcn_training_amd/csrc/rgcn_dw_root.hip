@@ -16,7 +16,10 @@ namespace rgcn {
 // workgroups fit a CU NEXT TO a workgroup of rgcn_tile_kernel: 5 GB of streaming reads and a tenth of a launch's MFMAs,
 // which the host runs on a side stream under the MFMA-bound dX launch instead of after it.
 constexpr int kRootBatch = 8;                    // k-steps per register batch (two batches in flight)
-constexpr int kRootMaxWaves = 1024;              // one wave per SIMD of the chip
+#ifndef RGCN_ROOT_MAX_WAVES
+#define RGCN_ROOT_MAX_WAVES 1024
+#endif
+constexpr int kRootMaxWaves = RGCN_ROOT_MAX_WAVES;      // 1024: one wave per SIMD of the chip
 constexpr int kRootSlabFloats = 64 * 64 + 4 * 64;   // accumulator + the four row-quarters' bias sums
 
 struct DwRootArgs {
