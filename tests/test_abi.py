@@ -64,3 +64,22 @@ def test_cpu_tensors_are_rejected():
     et = torch.tensor([0, 1])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         conv(x, ei, et)
+
+
+def test_binding_constants_match_the_header():
+    """The flag / activation / version constants of the ctypes binding against the #defines of include/rgcn_mi355x.h: a drift
+    would silently select other kernels (flags are a bit mask the library does not validate bit by bit)."""
+    import re
+    from scaling_rgcn_training_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "rgcn_mi355x.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(RGCN_[A-Z0-9_]+)\s+(\d+)u?\b", text)}
+    assert defs["RGCN_ABI_VERSION"] == _lib.ABI_VERSION
+    for name in ("POINTER_GATHER", "DW_RING", "DW_DIRECT", "EXACT_FP32", "DW_ROOT_ONLY", "SPLIT_PRODUCERS"):
+        assert defs["RGCN_FLAG_" + name] == getattr(_lib, "FLAG_" + name), name
+    flags = [v for k, v in defs.items() if k.startswith("RGCN_FLAG_")]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)      # distinct single bits
+    acts = {m.group(1): int(m.group(2)) for m in re.finditer(r"(RGCN_ACT_[A-Z]+)\s*=?\s*(\d+)", text)}
+    for name in ("NONE", "RELU", "SIGMOID"):
+        assert acts["RGCN_ACT_" + name] == getattr(_lib, "ACT_" + name), name
+
