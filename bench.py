@@ -190,8 +190,6 @@ def main():
     ap.add_argument("--width", type=int, default=HEADLINE[3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ladder", action="store_true")
-    ap.add_argument("--split-precision", action="store_true",
-                    help="forward / dX on the bf16x3 split-precision kernel and layout-1 plans (default: exact-fp32 MFMA kernel)")
     ap.add_argument("--split-producers", dest="split_producers", action="store_true", default=None,
                     help="forward / dX on the bf16x3 kernel whose producer waves split the rows (fp32-equivalent; tile 224)")
     ap.add_argument("--no-split-producers", dest="split_producers", action="store_false")
@@ -223,7 +221,6 @@ def main():
     log(f"rank {rank}/{world}: generating {n} nodes / {e} edges / {r} relations on {torch.cuda.get_device_name(dev)}")
     ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, d, d, dev)
     conv = RGCNConv(d, d, r).to(dev)
-    conv.split_precision = bool(args.split_precision)
     if args.split_producers is not None:
         conv.split_producers = bool(args.split_producers)
     with torch.no_grad():
@@ -314,7 +311,7 @@ def main():
     psb = [(_lib.plan_struct(p), p) for p in bps]
 
     kf = conv.kernel_flags
-    split_producers = bool(fps) and conv._use_split_producers(fps[0].chunk) and fps[0].layout == 0
+    split_producers = bool(fps) and conv._use_split_producers(fps[0].chunk)
     if split_producers:
         kf |= _lib.FLAG_SPLIT_PRODUCERS
 
@@ -391,7 +388,8 @@ def main():
                     "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic}
     roofline.update({"traffic_source": traffic_source, "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": kms,
                      "hbm_achieved_GBs": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
-                     "t_at_peak_ms": {"hbm": t_hbm * 1e3, "mfma_f32": t_mfma * 1e3}})
+                     "t_at_peak_ms": {"hbm": t_hbm * 1e3,
+                                      ("mfma_bf16x6" if split_producers and tile_ms >= kernel_ms["dw"] else "mfma_f32"): t_mfma * 1e3}})
     ms_per_step = dt / args.steps * 1e3
     step_bytes = sum(algorithmic_bytes(e, n, r, d, d).values())
     roofline_step = {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
@@ -404,7 +402,7 @@ def main():
     # (rgcn_tile_kernel) when the default producer-split bf16 x 3 kernel ran above, and vice versa -- on the same box right
     # after the main run, with its own plans
     alt = None
-    if world == 1 and (n, e, r, d) == HEADLINE and not args.no_ladder and not args.split_precision:
+    if world == 1 and (n, e, r, d) == HEADLINE and not args.no_ladder:
         main_mode = conv.split_producers
         try:
             with torch.no_grad():

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 12
+#define RGCN_ABI_VERSION 13
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -50,11 +50,10 @@ enum rgcn_act { RGCN_ACT_NONE = 0, RGCN_ACT_RELU = 1, RGCN_ACT_SIGMOID = 2 };
 #define RGCN_FLAG_DW_ROOT_ONLY 16u   /* rgcn_bwd_dw: d_root and d_bias only (the relations went to rgcn_bwd_dw_tiles) */
 #define RGCN_FLAG_SPLIT_PRODUCERS 32u /* rgcn_fwd / rgcn_bwd_dx: the bf16 x 3 kernel whose PRODUCER waves split the gathered rows
                                        * (fp32-equivalent: 24 significant bits on both operands, six bf16 products): 64 x 64 layers,
-                                       * 128-slot chunks, layout 0, tile <= 224; other shapes take the exact-fp32 kernel.
+                                       * 128-slot chunks, tile <= 224 (layout-1 plans: two teams of consumer waves); other shapes take the exact-fp32 kernel.
                                        * rgcn_bwd_dw_tiles: the same walk with both operands split into three bf16 pieces in registers
                                        * (six bf16 products, fp32 accumulation; same fp32-equivalence) */
-#define RGCN_FLAG_EXACT_FP32 8u     /* rgcn_fwd / rgcn_bwd_dx: the exact-fp32 MFMA kernel also where the split-precision
-                                     * (bf16 x 3, six products: fp32-equivalent) kernel applies: 64 x 64 on layout-1 plans */
+#define RGCN_FLAG_EXACT_FP32 8u     /* rgcn_fwd / rgcn_bwd_dx: the exact-fp32 MFMA kernel whatever else the flags ask for */
 
 enum rgcn_status {
     RGCN_OK = 0,
@@ -66,7 +65,9 @@ enum rgcn_status {
     RGCN_ERR_WORKSPACE = -6, /* workspace smaller than the *_workspace_bytes query */
     RGCN_ERR_DEVICE = -7,    /* current device is not gfx950 / no device */
     RGCN_ERR_ACT = -8,       /* unknown activation code */
-    RGCN_ERR_GRAPH = -9      /* rgcn_plan_build: an edge_index / edge_type value is out of range */
+    RGCN_ERR_GRAPH = -9,     /* rgcn_plan_build: an edge_index / edge_type value is out of range */
+    RGCN_ERR_ADDRESS = -10   /* rgcn_bwd_dw_tiles: a gathered matrix cannot be addressed through a buffer descriptor (2^24 rows or
+                              * 4 GiB and more): use rgcn_bwd_dw, whose kernels fall back to 64-bit pointers */
 };
 
 /* Graph plan in HBM, built once per graph (scaling_rgcn_training_amd/plan.py documents the layout;
@@ -81,10 +82,11 @@ typedef struct rgcn_plan {
     int32_t n_chunks;
     int32_t chunk;         /* edge slots per chunk: 64 or 128 (rows of one LDS ring slot of the forward / dX kernel) */
     int32_t n_units;       /* entries of rel_order */
-    int32_t layout;        /* 0: the rows of a (tile, relation) group are dealt over all its row tiles; 1 (chunk = 128): SPLIT
-                            * placement -- a chunk's rows are cut at a change of destination into slots [0, 64) and [64, 128),
-                            * so its two halves scatter into disjoint rows (chunk_flags bit 8: they do not) and the
-                            * split-precision forward / dX kernel gives each half to its own pair of waves */
+    int32_t layout;        /* 0: the rows of a (tile, relation) group are dealt over all its row tiles; 1 (chunk = 128): TEAM
+                            * placement -- a chunk's rows are cut at a change of destination into part A on its first
+                            * ceil(nt / 2) row tiles and part B on the others, so the two parts scatter into disjoint rows
+                            * (chunk_flags bit 8: they do not) and the forward / dX kernel of 64 x 64 layers gives each
+                            * part to its own team of consumer waves; same chunks and row-tile counts as layout 0 */
     int32_t reserved;
     const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
     const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */

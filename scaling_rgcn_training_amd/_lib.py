@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
@@ -26,6 +26,7 @@ EXPORTS = (
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ERR_ADDRESS = -10      # rgcn_bwd_dw_tiles: operands not addressable through a buffer descriptor
 FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT, FLAG_EXACT_FP32, FLAG_DW_ROOT_ONLY, FLAG_SPLIT_PRODUCERS = 1, 2, 4, 8, 16, 32
 
 
@@ -124,7 +125,16 @@ def load() -> C.CDLL:
 def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().rgcn_status_string(status).decode()
-        raise RgcnLibraryError(f"{what} failed with status {status}: {msg}")
+        err = RgcnLibraryError(f"{what} failed with status {status}: {msg}")
+        err.status = status
+        raise err
+
+
+def buffer_addressable(rows: int, ld: int) -> bool:
+    """Can a [rows, ld] fp32 matrix be gathered through a buffer descriptor (csrc/rgcn_kernels_shared.h buffer_bytes: 24-bit
+    row index, 32-bit offsets with the one-past-the-end padding row in range)?  The tile-major weight-gradient kernel
+    addresses both operands that way only; the other kernels fall back to 64-bit pointers."""
+    return rows < (1 << 24) and (rows + 1) * ld * 4 < 0xFFFFFF00
 
 
 def plan_struct(plan) -> RgcnPlanStruct:

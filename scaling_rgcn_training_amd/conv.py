@@ -39,10 +39,12 @@ def _rows16(t: Tensor, width: int) -> Tensor:
 # experiment overrides of the (tile, chunk) layout: read ONCE at import, never on the forward path
 _ENV_TILE = int(os.environ["RGCN_TILE"]) if "RGCN_TILE" in os.environ else None
 _ENV_CHUNK = int(os.environ["RGCN_CHUNK"]) if "RGCN_CHUNK" in os.environ else None
-_SPLIT_PRECISION_DEFAULT = os.environ.get("RGCN_SPLIT_PRECISION", "0") == "1"
 # forward / dX on the bf16 x 3 kernel whose PRODUCER waves split the gathered rows (csrc/rgcn_tile3p.hip):
 # fp32-equivalent arithmetic; layers padded to 64 x 64 on graphs dense enough for 128-slot chunks.  "1" / "0" / "auto"
 _SPLIT_PRODUCERS_DEFAULT = os.environ.get("RGCN_SPLIT_PRODUCERS", "1")
+# plans of those layers in the TEAM placement (plan layout 1, plan.team_placement): two teams of consumer waves per workgroup
+# accumulate the two destination-disjoint parts of every chunk side by side.  "0": layout 0 and the one-team kernel (round 2)
+_TEAM_LAYOUT_DEFAULT = os.environ.get("RGCN_TEAM_LAYOUT", "1") == "1"
 SPLIT_PRODUCERS_TILE = 224       # the largest tile whose fp32 accumulator fits beside the kernel's two 48 KiB ring slots
 DW_TILES_MIN_EDGES = 4_000_000
 
@@ -71,16 +73,6 @@ def layout_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: i
     from .plan import choose_layout
     tile, chunk = choose_layout(n_nodes, n_edges, num_relations, in_channels, out_channels)
     return (_ENV_TILE or tile), (_ENV_CHUNK or chunk)
-
-
-def split_for(in_channels: int, out_channels: int, n_nodes: int, n_edges: int, num_relations: int, tile: int, chunk: int) -> bool:
-    """Lay the plan out for the split-precision forward / dX kernel (plan layout 1)?  That kernel exists for layers padded
-    to 64 x 64 on 128-slot chunks and pays where a (tile, relation) group fills more than one 64-slot half."""
-    from .plan import padded_width
-    if chunk != 128 or padded_width(in_channels) != 64 or padded_width(out_channels) != 64:
-        return False
-    density = n_edges / max(1.0, float(n_nodes) * max(1, num_relations))
-    return density * tile > 64.0
 
 
 def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int = 0, num_relations: int = 1) -> int:
@@ -219,7 +211,8 @@ class _RGCNLayerFn(torch.autograd.Function):
         # dX kernel instead of adding their ~1 ms behind it.  The join is a stream wait, never a host sync.
         dwp = getattr(plans, "dw", None) if dctx is None else None
         tiles_path = (dwp is not None and need_w and plans.fwd.n_owned > 0 and
-                      not (flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)))
+                      not (flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)) and
+                      _lib.buffer_addressable(n, xp.shape[1]) and _lib.buffer_addressable(n, gp.shape[1]))
         tiles_part = side = None
         if tiles_path:
             tiles_part = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
@@ -326,15 +319,12 @@ class RGCNConv(nn.Module):
         self.dist: Optional[DistContext] = None
         self._dist_plans = None
         self.kernel_flags = 0     # RGCN_FLAG_* passed to every launch of this layer (tests pin kernel paths with it)
-        # True: lay the plans out for, and run forward / dX on, the split-precision (bf16 x 3, fp32-equivalent) kernel
-        # where it exists (64 x 64, dense groups).  Off by default: measured no faster than the exact-fp32 kernel
-        # (10.9 vs 10.6 ms per launch at the headline config).
-        self.split_precision = _SPLIT_PRECISION_DEFAULT
         self.dw_tiles = True      # d_weight by the tile-major kernel where it applies (_plans); False: relation-major kernels
         # forward / dX on the producer-split bf16 x 3 kernel where it applies (64 x 64, 128-slot chunks, single GPU): fp32-
         # equivalent arithmetic (24-bit operand significands, exact products, fp32 accumulation), 1 ms per step faster at
         # the headline config.  False (or RGCN_SPLIT_PRODUCERS=0): the exact-fp32 MFMA kernel everywhere
         self.split_producers = _SPLIT_PRODUCERS_DEFAULT == "1"
+        self.team_layout = _TEAM_LAYOUT_DEFAULT     # plans of such layers in the team placement (two consumer teams per workgroup)
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
             self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
@@ -388,12 +378,15 @@ class RGCNConv(nn.Module):
         n = x.shape[0]
         e = int(edge_type.shape[0])
         tile, chunk = self.layout(n, e)
-        split = self.split_precision and split_for(self.in_channels, self.out_channels, n, e, self.num_relations, tile, chunk)
+        split = self.team_layout and self._use_split_producers(chunk)       # plan layout 1 (team placement)
         if self.dist is None:
             # the tile-major weight-gradient kernel: 64 x 64 layers with few relations on graphs large enough to fill it
             from .plan import padded_width
+            # (that kernel gathers through buffer descriptors only: above 2^24 rows / 4 GiB the relation-major kernels run)
             dw_tiles = (self.dw_tiles and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64
-                        and self.num_relations <= 32 and e >= DW_TILES_MIN_EDGES and x.is_cuda)
+                        and self.num_relations <= 32 and e >= DW_TILES_MIN_EDGES and x.is_cuda
+                        and _lib.buffer_addressable(n, _round4(self.in_channels))
+                        and _lib.buffer_addressable(n, _round4(self.out_channels)))
             return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split,
                                       dw_tiles=dw_tiles)
         from .dist import cached_rank_plans
@@ -401,7 +394,7 @@ class RGCNConv(nn.Module):
 
     def _use_split_producers(self, chunk: int) -> bool:
         from .plan import padded_width
-        return (self.split_producers and not self.split_precision and chunk == 128 and not _ENV_TILE
+        return (self.split_producers and chunk == 128 and not _ENV_TILE
                 and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64)
 
     def layout(self, n_nodes: int, n_edges: int) -> Tuple[int, int]:
@@ -429,7 +422,7 @@ class RGCNConv(nn.Module):
         plans = self._plans(x, edge_index, edge_type)
         flags = self.kernel_flags
         first = plans.fwd if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
-        if first is not None and self._use_split_producers(first.chunk) and first.layout == 0:
+        if first is not None and self._use_split_producers(first.chunk):
             flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles; the library falls back where it does not fit
         return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist,
                                   _activation, _input_relu, _grad_premasked and _activation == "relu", flags)

@@ -19,6 +19,8 @@ namespace rgcn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));     // one operand of v_mfma_f32_16x16x32_bf16
 
 constexpr int kChunk = 64;          // edge slots per unit of the dW walk and per ring slot of the dW kernels (== RGCN_UNIT)
 constexpr int kThreads = 512;       // 8 waves: 0-3 producers, 4-7 consumers
@@ -38,6 +40,13 @@ __device__ __forceinline__ void wg_barrier() {
     // consumers: make sure their LDS reads/atomics have retired; producers: nothing pending on lgkm
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+}
+
+// two fp32 -> two bf16 (round to nearest even), lo -> bits 0..15, hi -> bits 16..31
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 // LDS-DMA: 16 B per lane from `gptr` (per lane) to lds_base + lane*16 (lds_base wave-uniform).

@@ -1,0 +1,428 @@
+// rgcn_dw_tile.hip -- weight gradients of 64 x 64 layers with at most 32 relations by a TILE-MAJOR walk (the gradient rows of
+// a tile staged in LDS once per relation quarter; a wave owns one relation for the whole launch), and the entry points
+// rgcn_dw_tiles_geometry / rgcn_dw_tiles_walk / rgcn_bwd_dw_tiles of include/rgcn_mi355x.h.
+#include "rgcn_kernels_shared.h"
+
+namespace rgcn {
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel, tile-major form (64 x 64, at most 32 relations, buffer-addressable operands)
+// ------------------------------------------------------------------------------------------------
+// The relation-major kernels above gather TWO rows per slot -- x[src] and the upstream gradient g[dst] -- although only
+// N gradient rows exist: E * 4 * out bytes of gathers (25.6 GB at the headline config) that no walk ORDER gets the caches
+// to serve.  Making the reuse structural means staging a tile's gradient rows in LDS and walking
+// tile-major -- and then the relation changes with every (tile, relation) group, which is why the accumulators have to be
+// somewhere that survives the whole walk.  Here they are: a wave owns ONE relation for the whole launch and keeps its
+// 64 x 64 accumulator in registers (64 VGPRs, as in the direct kernel); a workgroup = 8 waves = 8 relations, FOUR
+// workgroups (relation quarters) share a tile range, `walkers` ranges cover the graph.  Per tile: the workgroup's waves
+// DMA the tile's T = 304 gradient rows into one of two LDS buffers (2 x 76 KiB) a tile ahead, each wave walks the
+// 64-slot units of (tile, its relation) -- a contiguous stretch of rel_order -- loading x rows straight from global
+// memory into registers half a unit ahead (rgcn_dw_direct_kernel's pipeline) and reading the gradient rows from LDS.
+// Traffic: x gathers E * 4 * in + four sweeps of g (4 N * 4 * out) + indices = 37 GB instead of 55; one barrier per tile.
+// The root relation and the bias gradient stay with rgcn_dw_direct_kernel (RGCN_FLAG_DW_ROOT_ONLY): their x rows are
+// the tile's own.
+#ifndef RGCN_DW_ABL_NOBARRIER
+#define RGCN_DW_ABL_NOBARRIER 0
+#endif
+#ifndef RGCN_DW_TRUNC
+#define RGCN_DW_TRUNC 0
+#endif
+#ifndef RGCN_DW_ABL
+#define RGCN_DW_ABL 0      // timing-only ablations of rgcn_dw_tile_kernel<true>: 1 cached gathers, 2 no MFMAs, 4 no split arithmetic
+#endif
+#ifndef RGCN_DW_VECTOR_WALK
+#define RGCN_DW_VECTOR_WALK 0
+#endif
+#ifndef RGCN_DW_XCD_MAP
+#define RGCN_DW_XCD_MAP 1
+#endif
+constexpr int kDwTileT = 304;                    // gradient rows per LDS buffer = tile size of the plan this kernel walks
+constexpr int kDwTileWalkers = 64;               // tile ranges; x 4 relation quarters = 256 workgroups, one per CU
+constexpr int kDwTileMaxRel = 32;
+
+struct DwTileArgs {
+    const int* rel_order;   // of a plan with tile = kDwTileT, 64-slot chunks (unit == chunk), layout 0
+    const int* chunk_cnt;
+    const int* chunk_tile;
+    const int* slot_src;
+    const float* slot_w;
+    const int* slot_row;
+    const int* walk_ptr;    // [num_rel][walkers + 1]: rel_order positions where walker p's tiles of relation r begin
+    const float* x;
+    const float* g;
+    unsigned x_bytes, g_bytes;
+    float* slabs;           // [walkers][num_rel][64 * 64]
+    int ldx, ldg, dout4, n_tiles, n_owned, num_rel, walkers;
+};
+
+// SPLIT: the same walk with the contraction as a bf16 x 3 split of BOTH fp32 operands (x row values and weight * gradient
+// values -> three bf16 pieces each, split in registers by the wave that uses them; six v_mfma_f32_16x16x32_bf16 products
+// hh, hm, mh, hl, lh, mm, fp32 accumulation: 24 significant bits on both sides, as rgcn_tile3p_kernel).  A 64-slot unit is two
+// 32-row k-steps of that MFMA = the two halves of the register pipeline, with slot 32 h + 4 s + kq as k index 8 kq + s on both
+// operands (a sum over k does not care which slot sits where, only that A and B agree).  96 MFMAs of 16 cycles per half
+// against 256 of 32: the exact-fp32 form of this kernel is bound by the fp32 MFMA rate.
+template <bool SPLIT>
+__global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a) {
+    constexpr int T = kDwTileT, NP = 64, HS = 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][T][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if RGCN_DW_XCD_MAP
+    // the four relation quarters of a tile range on ONE XCD (workgroup b runs on XCD b % 8): they stage the same gradient rows
+    const int quarter = (blockIdx.x >> 3) & 3, p = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3);
+#else
+    const int quarter = blockIdx.x & 3, p = blockIdx.x >> 2;
+#endif
+    const int rel = 8 * quarter + wave;
+    const bool have = rel < a.num_rel;
+    const int t0 = (int)((long)p * a.n_tiles / a.walkers), t1 = (int)((long)(p + 1) * a.n_tiles / a.walkers);
+    if (t1 <= t0) return;
+    const int i0 = have ? ldc(a.walk_ptr, (long)rel * (a.walkers + 1) + p) : 0;
+    const int nun = have ? ldc(a.walk_ptr, (long)rel * (a.walkers + 1) + p + 1) - i0 : 0;
+    const int ml = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes), rg = make_rsrc(a.g, a.g_bytes);
+    const unsigned colb = 16u * (unsigned)ml;
+    const unsigned rbx = (unsigned)a.ldx * 4u, rbg = (unsigned)a.ldg * 4u;
+    const unsigned gcol = ml < a.dout4 ? colb : 0xFFFFFFF0u;     // columns beyond the width: out of range -> zeros
+    const unsigned grow = ml < a.dout4 ? rbg : 0u;
+    const int perm = kq * 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ia][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // tile t -> LDS buffer b: DMA instruction i moves rows 4 i .. 4 i + 3 (64 lanes x 16 bytes); rows past the end read zeros
+    auto dma_tile = [&](int t, int b) {
+        float* base = lds + b * T * NP;
+        for (int i = wave; i < T / 4; i += 8) {
+            const unsigned row = (unsigned)(t * T + 4 * i + kq);
+            dma16_buf(rg, __umul24(row, grow) + gcol, base + i * 4 * NP);
+        }
+    };
+    struct Idx {      // lane l: slot l of the unit
+        int h, g;
+        float w;
+    };
+    auto unit_of = [&](int k) { return ldc(a.rel_order, i0 + (k < nun ? k : (nun > 0 ? nun - 1 : 0))); };
+    auto load_idx = [&](int unit) {
+        const size_t base = (size_t)unit * kChunk + lane;
+        return Idx{a.slot_src[base], a.slot_row[base], a.slot_w[base]};
+    };
+    auto issue_half = [&](f32x4 (&a4)[HS], const Idx& ix, int h) {
+        int ih[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) ih[s] = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), ix.h);
+        if (RGCN_DW_ABL & 1)       // (timing only: every gather hits rows 0..63 -- no HBM traffic for x)
+#pragma unroll
+            for (int s = 0; s < HS; ++s) ih[s] &= 63;
+#pragma unroll
+        for (int s = 0; s < HS; ++s)
+            a4[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)ih[s], rbx) + colb), 0, 0));
+    };
+    // half a unit: 8 k-steps of 4 rows; gradient rows from the LDS tile (row ids local to the tile, padding clamped: its
+    // weight is 0 and every LDS word is a finite number)
+    auto compute_half = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, int nks, const float* gbuf, int tile_row0) {
+        const unsigned loc = (unsigned)(ix.g - tile_row0);
+        const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));    // byte offset of this lane's slot row
+        float wv[HS];
+        f32x4 g4[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            wv[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), __builtin_bit_cast(int, ix.w)));
+            const int o = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), goff);
+            g4[s] = *(const f32x4*)((const char*)gbuf + o + colb);
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            if (2 * h + gi < ngrp) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int s = 4 * gi + t;
+                    // (cutting a unit's tail at the 4-row k-step instead of the 16-row group -- ~6 % fewer MFMAs -- measured
+                    // 1 % SLOWER: 8.25 against 8.16 ms; the walk is not bound by its MFMA count.  Knob: RGCN_DW_KSTEP_GATE)
+                    if (RGCN_DW_KSTEP_GATE && HS * h + s >= nks) break;
+                    f32x4 bv = g4[s] * wv[s];
+                    asm volatile("s_nop 4" : "+v"(bv));       // VALU write -> asm MFMA operand (see rgcn_dw_direct_kernel)
+#pragma unroll
+                    for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb)
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[ia][jb]) : "v"(a4[s][ia]), "v"(bv[jb]));
+                }
+            }
+        }
+    };
+
+    // v0, v1 -> three packed bf16 pairs (low half = v0), round-to-nearest pieces: v = h + m + l to 24 bits
+    auto split_pair = [](float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+        if (RGCN_DW_ABL & 4) {      // (timing only: no split arithmetic)
+            h = __float_as_uint(v0);
+            m = __float_as_uint(v1);
+            l = h ^ m;
+            return;
+        }
+#if RGCN_DW_TRUNC      // pieces by truncation (v_perm_b32 packs two upper halves; exact as well): measured, see DESIGN.md 4.3
+        auto pk = [](float lo, float hi) { return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u); };
+        auto top = [](float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); };
+        h = pk(v0, v1);
+        v0 -= top(v0); v1 -= top(v1);
+        m = pk(v0, v1);
+        v0 -= top(v0); v1 -= top(v1);
+        l = pk(v0, v1);
+        return;
+#endif
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
+        v0 -= __uint_as_float(h << 16);
+        v1 -= __uint_as_float(h & 0xFFFF0000u);
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m) : "v"(v0), "v"(v1));
+        v0 -= __uint_as_float(m << 16);
+        v1 -= __uint_as_float(m & 0xFFFF0000u);
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(v0), "v"(v1));
+    };
+    // half a unit as ONE 32-row k-step (a half with no valid slot is skipped; padding slots inside one have weight 0)
+    auto compute_half3 = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {
+        if (2 * h >= ngrp) return;
+        const unsigned loc = (unsigned)(ix.g - tile_row0);
+        const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));
+        float wv[HS];
+        f32x4 g4[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            wv[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), __builtin_bit_cast(int, ix.w)));
+            const int o = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), goff);
+            g4[s] = *(const f32x4*)((const char*)gbuf + o + colb);
+        }
+        u32x4 ap[3][4];      // [piece][ia]: 8 bf16 = k index 8 kq + 0..7 of input channel 4 ml + ia
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                unsigned h_, m_, l_;
+                split_pair(a4[2 * jp][ia], a4[2 * jp + 1][ia], h_, m_, l_);
+                ap[0][ia][jp] = h_; ap[1][ia][jp] = m_; ap[2][ia][jp] = l_;
+            }
+        constexpr int pa[6] = {2, 1, 1, 0, 0, 0}, pb[6] = {0, 1, 0, 2, 1, 0};      // small products first
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            u32x4 bp[3];
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                unsigned h_, m_, l_;
+                split_pair(g4[2 * jp][jb] * wv[2 * jp], g4[2 * jp + 1][jb] * wv[2 * jp + 1], h_, m_, l_);
+                bp[0][jp] = h_; bp[1][jp] = m_; bp[2][jp] = l_;
+            }
+            if (RGCN_DW_ABL & 2) {      // (timing only: no MFMAs; the pieces stay alive)
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+                    asm volatile("" ::"v"(ap[0][ia]), "v"(ap[1][ia]), "v"(ap[2][ia]), "v"(bp[0]), "v"(bp[1]), "v"(bp[2]));
+                continue;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+                    acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[pa[q]][ia]),
+                                                                          __builtin_bit_cast(bf16x8, bp[pb[q]]), acc[ia][jb], 0, 0, 0);
+        }
+    };
+
+    // The halves are computed under conditions (a half without valid slots is skipped), and loads whose uses all sit in later
+    // blocks get SUNK there by the optimiser -- issued right in front of their first use, their whole latency exposed (that is
+    // where the second half's eight row loads of every unit were until this was found: the ISA showed them behind half 0's
+    // MFMAs, not at the top of the iteration; sched_barrier only binds the scheduler inside a block).  A compiler-level memory
+    // clobber after each batch keeps the loads where issue_half puts them: a read cannot be moved across it.
+    auto pin_loads = [] { asm volatile("" ::: "memory"); };
+    dma_tile(t0, 0);
+    int k = 0;
+    int uid_cur = unit_of(0), uid_nxt = unit_of(1), uid_nn = unit_of(2);
+    int cnt_cur = ldc(a.chunk_cnt, uid_cur), tile_cur = nun > 0 ? ldc(a.chunk_tile, uid_cur) : t1;
+    int cnt_nxt = ldc(a.chunk_cnt, uid_nxt), tile_nxt = nun > 1 ? ldc(a.chunk_tile, uid_nxt) : t1;
+#if RGCN_DW_VECTOR_WALK
+    // Inside the walk the three per-unit words (unit id, slot count, tile) come by VECTOR loads of a uniform address: scalar
+    // loads return out of order, so the first LDS operation of the next unit -- its wait is lgkmcnt(0) -- would wait for the
+    // scalar loads issued a few instructions earlier, a full L2 round trip per unit; vector loads retire in order and are
+    // waited for by count, a whole unit after they were issued.
+    const __amdgpu_buffer_rsrc_t r_ord = make_rsrc(a.rel_order, 0xFFFFFFFCu), r_cnt = make_rsrc(a.chunk_cnt, 0xFFFFFFFCu),
+                                 r_til = make_rsrc(a.chunk_tile, 0xFFFFFFFCu);
+    auto ldv = [](__amdgpu_buffer_rsrc_t r, int idx) { return __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0); };
+#endif
+    Idx ix_cur = load_idx(uid_cur), ix_nxt = load_idx(uid_nxt);
+    f32x4 s0[HS], s1[HS];
+    if (nun > 0) issue_half(s0, ix_cur, 0);
+    constexpr int kInFlight = RGCN_DW_VECTOR_WALK ? 14 : 11;      // 8 row loads + 3 index loads (+ 3 walk words)
+    bool walked = nun > 0;      // at least kInFlight vector-memory operations were issued after the pending tile's DMAs
+    for (int t = t0; t < t1; ++t) {
+        // The DMAs of tile t were issued a tile ago (or in the prologue).  If the wave has walked a unit since (or issued the
+        // prologue's loads), more than kInFlight younger operations exist and at most kInFlight are in flight at a unit boundary (8 row
+        // loads + 3 index loads of the unit after next + the walk words): a counted wait retires the DMAs and leaves the prefetches alone.  A wave
+        // without units in between (an empty relation) has nothing younger to count: it waits for everything.
+        if (walked) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !RGCN_DW_ABL_NOBARRIER      // (timing only: the waves of a workgroup run free -- what the tile lockstep costs)
+        wg_barrier();          // tile t landed for every wave; every wave is done with the buffer tile t + 1 goes to
+#endif
+        const int b = (t - t0) & 1;
+        if (t + 1 < t1) dma_tile(t + 1, b ^ 1);
+        walked = false;
+        const float* gbuf = lds + b * T * NP;
+        while (k < nun && tile_cur == t) {
+            const int ngrp = (cnt_cur + 15) >> 4, nks = (cnt_cur + 3) >> 2;
+            walked = true;
+            issue_half(s1, ix_cur, 1);
+            pin_loads();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SPLIT) compute_half3(s0, ix_cur, 0, ngrp, gbuf, t * T);
+            else compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
+            __builtin_amdgcn_sched_barrier(0);
+            const Idx ix_nn = load_idx(uid_nn);
+            issue_half(s0, ix_nxt, 0);
+            pin_loads();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SPLIT) compute_half3(s1, ix_cur, 1, ngrp, gbuf, t * T);
+            else compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
+            __builtin_amdgcn_sched_barrier(0);
+            ++k;
+            ix_cur = ix_nxt;
+            ix_nxt = ix_nn;
+            uid_cur = uid_nxt;
+            uid_nxt = uid_nn;
+#if RGCN_DW_VECTOR_WALK
+            uid_nn = ldv(r_ord, i0 + (k + 2 < nun ? k + 2 : nun - 1));
+            cnt_cur = __builtin_amdgcn_readfirstlane(cnt_nxt);
+            tile_cur = k < nun ? __builtin_amdgcn_readfirstlane(tile_nxt) : t1;
+            cnt_nxt = ldv(r_cnt, uid_nxt);
+            tile_nxt = ldv(r_til, uid_nxt);       // (a clamped unit's tile is never looked at: tile_cur = t1 past the end)
+#else
+            uid_nn = unit_of(k + 2);
+            cnt_cur = cnt_nxt;
+            tile_cur = k < nun ? tile_nxt : t1;
+            cnt_nxt = ldc(a.chunk_cnt, uid_nxt);
+            tile_nxt = k + 1 < nun ? ldc(a.chunk_tile, uid_nxt) : t1;
+#endif
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the accumulators are read by plain stores the compiler schedules: keep them clear of the last asm MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (have) {
+        float* slab = a.slabs + ((size_t)p * a.num_rel + rel) * (64 * 64);
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(4 * (4 * kq + r) + ia) * NP + 4 * ml + jb] = acc[ia][jb][r];
+    }
+}
+
+// walk_ptr[r][p] = first position in rel_order (sorted by (relation, tile)) of a unit of relation r whose tile is
+// >= p * n_tiles / walkers; one thread per entry, binary search (integer work, once per plan)
+__global__ void rgcn_dw_walk_table_kernel(const int* __restrict__ rel_order, const int* __restrict__ chunk_rel,
+                                          const int* __restrict__ chunk_tile, int n_units, int n_tiles, int num_rel, int walkers,
+                                          int* __restrict__ walk_ptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_rel * (walkers + 1)) return;
+    const int r = i / (walkers + 1), p = i - r * (walkers + 1);
+    const long target = (long)r * n_tiles + (long)p * n_tiles / walkers;
+    int lo = 0, hi = n_units;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = rel_order[mid];                        // 64-slot chunks: unit == chunk
+        if ((long)chunk_rel[c] * n_tiles + chunk_tile[c] < target) lo = mid + 1; else hi = mid;
+    }
+    walk_ptr[i] = lo;
+}
+
+// d_weight[r] = sum over the walkers' slabs, in walker order (bitwise reproducible)
+__global__ void rgcn_dw_tile_reduce_kernel(const float* __restrict__ slabs, int walkers, int num_rel, int din, int dout,
+                                           float* __restrict__ d_weight) {
+    const int r = blockIdx.x;
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < din * dout; e += gridDim.y * blockDim.x) {
+        const int kk = e / dout, n = e - kk * dout;
+        float sum = 0.f;
+        for (int w = 0; w < walkers; ++w) sum += slabs[((size_t)w * num_rel + r) * (64 * 64) + kk * 64 + n];
+        d_weight[(size_t)r * din * dout + e] = sum;
+    }
+}
+
+// slabs -> gradients, fixed summation order (block index ascending) => bitwise reproducible.
+// grid = (R' + 2, parts): blockIdx.x = relation (R' = root, R'+1 = bias), blockIdx.y = slice of the elements.
+
+}  // namespace rgcn
+
+using namespace rgcn;
+
+extern "C" int rgcn_dw_tiles_geometry(int* tile, int* walkers, int* max_relations) {
+    if (tile) *tile = kDwTileT;
+    if (walkers) *walkers = kDwTileWalkers;
+    if (max_relations) *max_relations = kDwTileMaxRel;
+    return RGCN_OK;
+}
+
+extern "C" int rgcn_dw_tiles_walk(const rgcn_plan_t* plan, int32_t* walk_ptr, void* stream) {
+    int st;
+    if ((st = check_device()) != RGCN_OK) return st;
+    if ((st = check_plan(plan)) != RGCN_OK) return st;
+    if (walk_ptr == nullptr) return RGCN_ERR_NULL;
+    if (plan->tile != kDwTileT || plan->chunk != 64 || plan->layout != 0 || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
+    const int n = plan->num_relations * (kDwTileWalkers + 1);
+    hipLaunchKernelGGL(rgcn_dw_walk_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan->rel_order,
+                       plan->chunk_rel, plan->chunk_tile, plan->n_units, plan->n_tiles, plan->num_relations, kDwTileWalkers, walk_ptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t rgcn_bwd_dw_tiles_workspace_bytes(int num_relations) {
+    return num_relations > 0 ? sizeof(float) * (size_t)kDwTileWalkers * num_relations * 64 * 64 : 0;
+}
+
+extern "C" int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_ptr, const float* x, int ldx, int din, const float* g,
+                                 int ldg, int dout, void* workspace, size_t workspace_bytes, float* d_weight, unsigned flags,
+                                 void* stream) {
+    int st = check_plan(plan);
+    if (st != RGCN_OK) return st;
+    if (!walk_ptr || !x || !g || !workspace || !d_weight) return RGCN_ERR_NULL;
+    if ((st = check_stride(ldx, din)) != RGCN_OK) return st;
+    if ((st = check_stride(ldg, dout)) != RGCN_OK) return st;
+    if (padded_width(din) != 64 || padded_width(dout) != 64) return RGCN_ERR_WIDTH;
+    if (plan->tile != kDwTileT || plan->chunk != 64 || plan->layout != 0 || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
+    if (workspace_bytes < rgcn_bwd_dw_tiles_workspace_bytes(plan->num_relations)) return RGCN_ERR_WORKSPACE;
+    if ((st = check_device()) != RGCN_OK) return st;
+    DwTileArgs a;
+    a.rel_order = plan->rel_order;
+    a.chunk_cnt = plan->chunk_cnt;
+    a.chunk_tile = plan->chunk_tile;
+    a.slot_src = plan->slot_src;
+    a.slot_w = plan->slot_w;
+    a.slot_row = plan->slot_row;
+    a.walk_ptr = walk_ptr;
+    a.x = x;
+    a.g = g;
+    a.x_bytes = buffer_bytes(plan->n_nodes, ldx, flags);
+    a.g_bytes = buffer_bytes(plan->n_owned, ldg, flags);
+    if (a.x_bytes == 0 || a.g_bytes == 0) return RGCN_ERR_ADDRESS;    // this kernel addresses through buffer descriptors only
+    a.slabs = (float*)workspace;
+    a.ldx = ldx;
+    a.ldg = ldg;
+    a.dout4 = (dout + 3) / 4;
+    a.n_tiles = plan->n_tiles;
+    a.n_owned = plan->n_owned;
+    a.num_rel = plan->num_relations;
+    a.walkers = kDwTileWalkers;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = sizeof(float) * 2 * kDwTileT * 64;
+    const bool split = (flags & RGCN_FLAG_SPLIT_PRODUCERS) != 0;
+    hipError_t e = split ? allow_full_lds<rgcn_dw_tile_kernel<true>>() : allow_full_lds<rgcn_dw_tile_kernel<false>>();
+    if (e != hipSuccess) return (int)e;
+    // walkers without tiles leave their slabs untouched: clear what the reduction reads
+    e = hipMemsetAsync(workspace, 0, rgcn_bwd_dw_tiles_workspace_bytes(plan->num_relations), s);
+    if (e != hipSuccess) return (int)e;
+    if (split) hipLaunchKernelGGL(rgcn_dw_tile_kernel<true>, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(rgcn_dw_tile_kernel<false>, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+    if ((st = (int)hipGetLastError()) != 0) return st;
+    hipLaunchKernelGGL(rgcn_dw_tile_reduce_kernel, dim3(plan->num_relations, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs,
+                       kDwTileWalkers, plan->num_relations, din, dout, d_weight);
+    return (int)hipGetLastError();
+}

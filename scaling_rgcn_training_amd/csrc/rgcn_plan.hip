@@ -351,12 +351,9 @@ __global__ void group_sizes_kernel(const u32* __restrict__ gstart, u32 n_groups,
     const u32 cnt = gstart[g + 1] - gstart[g];
     const u32 nt = (cnt + 15u) / 16u;
     gch[g] = (cnt + chunk - 1u) / chunk;
-    if (layout == 0) {
-        gun[g] = (nt + 3u) / 4u;
-    } else {            // split placement: a chunk range of more than 64 rows always spans both 64-slot units
-        const u32 rem = cnt % 128u;
-        gun[g] = 2u * (cnt / 128u) + (rem == 0 ? 0u : (rem > 64u ? 2u : 1u));
-    }
+    // both layouts put the rows of a chunk on contiguous row tiles from tile 0 and use ceil(cnt / 16) tiles per group
+    (void)layout;
+    gun[g] = (nt + 3u) / 4u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,8 +372,8 @@ __global__ void fill_slots_kernel(u32 n_slots, u32 n_nodes, u32 tile, int32_t* _
 
 // Layout 0: row j of a group (sorted by destination) goes to MFMA row tile (j mod nt), position (j div nt), nt = ceil(n / 16):
 // every tile stays sorted by destination and a run of c equal destinations is spread over c different tiles.
-// Layout 1 (plan.split_placement): chunk c of the group takes its rows [128 c, 128 c + 128); more than 64 of them are cut at
-// split[chunk] into part 0 (dealt over row tiles 0..3) and part 1 (tiles 4..), so the chunk's halves hold disjoint destinations.
+// Layout 1 (plan.team_placement): chunk c of the group takes its rows [128 c, 128 c + 128) on nt = ceil(n_c / 16) row tiles, cut
+// at split[chunk] into part A (dealt over the first ceil(nt / 2) row tiles) and part B (the others): disjoint destinations.
 __global__ void place_kernel(const u64* __restrict__ ukeys, const u32* __restrict__ uvals, u32 n, const u32* __restrict__ gid,
                              const u32* __restrict__ gstart, const u32* __restrict__ chunk_base, u32 chunk, u32 layout,
                              const u32* __restrict__ split, KeyLayout kl, int32_t* __restrict__ slot_src,
@@ -394,18 +391,14 @@ __global__ void place_kernel(const u64* __restrict__ ukeys, const u32* __restric
         const u32 cidx = rank / 128u, jc = rank % 128u;
         const u32 left = cnt - cidx * 128u, n_c = left < 128u ? left : 128u;
         const u32 c = chunk_base[g] + cidx;
+        const u32 nt = (n_c + 15u) / 16u, na = (nt + 1u) / 2u, nb = nt - na;
+        const u32 sp = split[c];
         u32 in_chunk;
-        if (n_c <= 64u) {
-            const u32 nt = (n_c + 15u) / 16u;
-            in_chunk = (jc % nt) * 16u + jc / nt;
+        if (jc < sp) {
+            in_chunk = (jc % na) * 16u + jc / na;
         } else {
-            const u32 sp = split[c];
-            if (jc < sp) {
-                in_chunk = (jc % 4u) * 16u + jc / 4u;
-            } else {
-                const u32 j1 = jc - sp, nt1 = (n_c - sp + 15u) / 16u;
-                in_chunk = 64u + (j1 % nt1) * 16u + j1 / nt1;
-            }
+            const u32 j1 = jc - sp;
+            in_chunk = (na + j1 % nb) * 16u + j1 / nb;
         }
         slot = (size_t)c * 128u + in_chunk;
     }
@@ -437,27 +430,29 @@ __global__ void chunk_meta_kernel(const u32* __restrict__ chunk_base, const u32*
         chunk_cnt[c] = (int32_t)((left < per ? left : per) * 16u);
     } else {
         const u32 left = cnt - idx * 128u, n_c = left < 128u ? left : 128u;
-        if (n_c <= 64u) {
-            chunk_cnt[c] = (int32_t)(((n_c + 15u) / 16u) * 16u);
+        const u32 nt = (n_c + 15u) / 16u, na = (nt + 1u) / 2u, nb = nt - na;
+        chunk_cnt[c] = (int32_t)(nt * 16u);
+        if (nt <= 1u) {
             split[c] = n_c;
         } else {
-            // cut at the run boundary closest to ceil(n_c / 2) inside [n_c - 64, 64]: mid, mid - 1, mid + 1, mid - 2, ...
+            // cut at the run boundary closest to the middle of [max(1, n_c - 16 nb), min(n_c - 1, 16 na)]: mid, mid - 1, mid + 1, ...
             const u64* rows = ukeys + gstart[g] + (size_t)idx * 128u;
             const u64 dmask = (1ull << kl.dstl_bits) - 1ull;
             auto dst_of = [&](u32 j) { return (rows[j] >> kl.src_bits) & dmask; };
-            const int mid = (int)((n_c + 1u) / 2u), lo_s = (int)n_c - 64 > 1 ? (int)n_c - 64 : 1, hi_s = (int)n_c - 1 < 64 ? (int)n_c - 1 : 64;
+            const int lo_s = (int)n_c - 16 * (int)nb > 1 ? (int)n_c - 16 * (int)nb : 1;
+            const int hi_s = (int)n_c - 1 < 16 * (int)na ? (int)n_c - 1 : 16 * (int)na;
+            const int mid = (lo_s + hi_s + 1) / 2;
             int sp = -1;
-            for (int k = 0; k < 64 && sp < 0; ++k) {
+            for (int k = 0; k <= 16 && sp < 0; ++k) {
                 const int a = mid - k, b = mid + k;
                 if (a >= lo_s && a <= hi_s && dst_of((u32)a - 1u) != dst_of((u32)a)) sp = a;
                 else if (k > 0 && b >= lo_s && b <= hi_s && dst_of((u32)b - 1u) != dst_of((u32)b)) sp = b;
             }
-            if (sp < 0) {      // one destination's run covers the whole window: the halves share it
-                sp = mid < lo_s ? lo_s : (mid > hi_s ? hi_s : mid);
+            if (sp < 0) {      // one destination's run covers the whole window: the parts share it
+                sp = mid;
                 flags = 256;
             }
             split[c] = (u32)sp;
-            chunk_cnt[c] = (int32_t)((4u + (n_c - (u32)sp + 15u) / 16u) * 16u);
         }
     }
     chunk_rel[c] = (int32_t)(gkey[g] & ((1u << kl.rel_bits) - 1u));

@@ -22,8 +22,6 @@
 
 namespace rgcn {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
 // timing-only ablations of diagnostic builds (wrong results): 1 producers load nothing, 2 consumers skip their MFMAs,
 // 4 consumers skip the accumulator read-modify-write, 8 producers skip the split (planes = raw halves)
 #ifndef RGCN_P3_ABL
@@ -275,13 +273,29 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileArgs a) {
+// TEAMS: 1 = every consumer wave sees every row tile of a chunk (any plan layout); 2 = two teams of consumer waves, team A on
+//        the first ceil(nt / 2) row tiles of a chunk and team B on the others -- LAYOUT-1 plans only (plan.team_placement: the
+//        two parts of a chunk hold disjoint destinations, so the teams never touch the same accumulator row).
+// NCT:   16-column tiles a consumer wave owns (1: four column owners per team, 2: two).
+// Consumer waves: TEAMS * 4 / NCT (4 or 8) beside the 4 producer waves.
+template <int TEAMS, int NCT>
+struct P3Cfg {
+    static constexpr int kConsumers = TEAMS * 4 / NCT;
+    static constexpr int kThreads = 64 * (4 + kConsumers);
+    static constexpr int kWavesPerSimd = (4 + kConsumers) / 4;
+};
+
+template <int TEAMS, int NCT>
+__global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, NCT>::kWavesPerSimd)) rgcn_tile3p_kernel(const TileArgs a) {
     constexpr int LDO = kP3LDO;
+    constexpr int kThreadsAll = P3Cfg<TEAMS, NCT>::kThreads;
+    constexpr int kConsumers = P3Cfg<TEAMS, NCT>::kConsumers;
+    constexpr int CG = 4 / NCT;                                    // column groups (consumer waves) per team
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* out_lds = lds;                                          // [tile + 1][LDO]  (row `tile`: dummy)
     char* ring = (char*)(lds + (a.tile + 1) * LDO);                // [2][3][128][128 B]
-    float* wring = (float*)(ring + 2 * kP3SlotBytes);              // [2][128]
-    int* dring = (int*)(wring + 2 * kP3CH);                        // [2][128]
+    float* wring = (float*)(ring + 2 * kP3SlotBytes);              // [2][128] pairs {weight, run metadata}
+    int* dring = (int*)(wring + 2 * kP3CH);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -293,27 +307,32 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
     const int c0 = ldc(a.tile_ptr, tile0);
     const int nch = ldc(a.tile_ptr, tile1) - c0;
 
-    for (int i = tid; i < (a.tile + 1) * LDO; i += kP3Threads) {
+    for (int i = tid; i < (a.tile + 1) * LDO; i += kThreadsAll) {
         const int col = i % LDO;
         out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
     }
 
     if (wave >= 4) {
-        // ---- consumers: wave cw owns output columns 16 cw .. 16 cw + 15 of every row ----------------------------------
+        // ---- consumers: wave cw = (team, column group cg) owns output columns 16 NCT cg .. + 16 NCT - 1 of its team's rows ----
         const int cw = wave - 4;
+        const int team = cw / CG, cg = cw % CG;
         const int rowl = lane & 15, kq = lane >> 4;
-        const unsigned col4_bytes = (unsigned)(16 * cw + 4 * kq) * 4u;     // Y^T layout: four consecutive columns of row rowl
-        const unsigned col1_bytes = (unsigned)(16 * cw + rowl) * 4u;       // Y layout: column rowl of rows 4 kq + i
-        // W planes of this wave's column tile: packed3[((((rel * 2 + c) * 3 + pl) * 2 + ct) * 2 + s) * 64 + lane]
-        const uint4* wp4 = (const uint4*)a.wp + (size_t)((cw >> 1) * 3 * 2 * 2 + (cw & 1) * 2) * 64 + lane;
+        const unsigned col4_bytes = (unsigned)(16 * NCT * cg + 4 * kq) * 4u;     // Y^T layout: four consecutive columns of row rowl
+        const unsigned col1_bytes = (unsigned)(16 * NCT * cg + rowl) * 4u;       // Y layout: column rowl of rows 4 kq + i
+        // W planes of this wave's column tiles: packed3[((((rel * 2 + c) * 3 + pl) * 2 + ct) * 2 + s) * 64 + lane], column
+        // 32 c + 16 ct + (lane & 15): fragment (ct, s) of a plane sits 2048 ct + 1024 s bytes behind the plane's first one
+        const int wc = NCT == 1 ? (cg >> 1) : cg, wct0 = NCT == 1 ? (cg & 1) : 0;
+        const uint4* wp4 = (const uint4*)a.wp + (size_t)(wc * 3 * 2 * 2 + wct0 * 2) * 64 + lane;
         auto wptr = [&](int rel, int pl) { return (const f32x4*)(wp4 + ((size_t)rel * kP3FragsPerRel + pl * 4) * 64); };
-        f32x4 wcur[3][2], wnext[3][2];
+        f32x4 wcur[NCT][3][2], wnext[NCT][3][2];
         int rel_cur = ldc(a.chunk_rel, c0);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            wcur[pl][0] = wptr(rel_cur, pl)[0];
-            wcur[pl][1] = wptr(rel_cur, pl)[64];
-        }
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                wcur[ct][pl][0] = wptr(rel_cur, pl)[128 * ct];
+                wcur[ct][pl][1] = wptr(rel_cur, pl)[128 * ct + 64];
+            }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire these loads in the compiler's scoreboard
         int cnt_pre = ldc(a.chunk_cnt, c0);
         int flags_pre = ldc(a.chunk_flags, c0);
@@ -322,8 +341,12 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
         auto prefetch_rel = [&](int rel) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                prefetch16<0>(wnext[pl][0], wptr(rel, pl));
-                prefetch16<1024>(wnext[pl][1], wptr(rel, pl));
+                prefetch16<0>(wnext[0][pl][0], wptr(rel, pl));
+                prefetch16<1024>(wnext[0][pl][1], wptr(rel, pl));
+                if constexpr (NCT == 2) {
+                    prefetch16<2048>(wnext[1][pl][0], wptr(rel, pl));
+                    prefetch16<3072>(wnext[1][pl][1], wptr(rel, pl));
+                }
             }
         };
         bool pending = rel_n1 != rel_cur;
@@ -335,11 +358,11 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
         unsigned long long sc_meta = 0, sc_comp = 0, sc_swap = 0, sc_bar = 0;
 #endif
         for (int it = 0; it < nch; ++it) {
-            P3S(t0);
+            P3S(t0s);
             const int chunk = c0 + it;
             const int buf = it & 1;
             const int cnt = cnt_pre;
-            const int flags = flags_pre & 0xFF;
+            const int flags_all = flags_pre;
             const int rel_next = rel_n1;
             const int rel_next2 = rel_n2;
             if (it + 1 < nch) {
@@ -350,16 +373,30 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
             if (it + 3 < nch) rel_n2 = ldc(a.chunk_rel, chunk + 3);
             const bool swap_b = pending;
             const int nrt = (cnt + 15) >> 4;
+            // this wave's row tiles of the chunk: [t0, t0 + n)
+            int t0 = 0, n = nrt;
+            bool serial = false;                // a chunk whose parts share a destination: team A takes all of it, tile by tile
+            if constexpr (TEAMS == 2) {
+                const int na = (nrt + 1) >> 1;
+                serial = (flags_all & 256) != 0;
+                if (serial) {
+                    n = team == 0 ? nrt : 0;
+                } else {
+                    t0 = team == 0 ? 0 : na;
+                    n = team == 0 ? na : nrt - na;
+                }
+            }
+            const int flags = (flags_all >> t0) & ((1 << n) - 1);
 #ifdef RGCN_P3_STAMPS
             asm volatile("" ::"s"(cnt), "s"(rel_next), "s"(flags));
 #endif
-            P3S(t1);
-            // this lane's operand addresses of row tile 0: plane pl at + pl * 16 KiB, row tile t at + t * 2 KiB (immediates)
+            P3S(t1s);
+            // this lane's operand addresses of its first row tile: plane pl at + pl * 16 KiB, row tile t at + t * 2 KiB (immediates)
             const char* xrow[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                xrow[s] = ring + buf * kP3SlotBytes + rowl * 128 + (((4 * s + kq) ^ ((rowl >> 1) & 7)) << 4);
-            const int2* mb = (const int2*)wring + buf * kP3CH;          // {weight bits, run metadata} per slot
+                xrow[s] = ring + buf * kP3SlotBytes + t0 * 2048 + rowl * 128 + (((4 * s + kq) ^ ((rowl >> 1) & 7)) << 4);
+            const int2* mb = (const int2*)wring + buf * kP3CH + t0 * 16;          // {weight bits, run metadata} per slot
             struct Ops {
                 bf16x8 pl[3][2];    // [plane][k-step]: 8 bf16 of row rowl, k = 32 s + 8 kq + (0..7)
                 float w1;
@@ -384,29 +421,29 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
                 return (float*)((char*)out_lds + (__umul24((unsigned)d, (unsigned)(LDO * 4)) + col_bytes));
             };
             constexpr int px[6] = {0, 0, 1, 0, 2, 1}, pwl[6] = {0, 1, 0, 2, 0, 1};      // x plane, W plane: hh hm mh hl lh mm
-            // six products of one half (k-step s) of a row tile, Y^T orientation: a lane ends with 4 consecutive columns of a row
-            auto mfma_half = [&](const Ops& o, f32x4 y, int s) {
+            // six products of one half (k-step s) of a row tile and column tile ct, Y^T orientation: a lane ends with 4
+            // consecutive columns of a row
+            auto mfma_half = [&](const Ops& o, f32x4 y, int s, int ct) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
                     if (RGCN_P3_ABL & 2) {
                         y += __builtin_bit_cast(f32x4, o.pl[px[q]][s]);
                         continue;
                     }
-                    y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[pwl[q]][s]), o.pl[px[q]][s], y, 0, 0, 0);
+                    y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[ct][pwl[q]][s]), o.pl[px[q]][s], y, 0, 0, 0);
                 }
                 return y;
             };
-            // ---- chunks without repeated destinations inside a row tile: straight-line, operands LA tiles ahead ------------
+            // ---- row tiles without repeated destinations: straight-line, operands LA tiles ahead -----------------------------
             // (Reading tile t + 1's accumulator row BEFORE tile t is stored -- with the lane's own previous value forwarded
             // where the two addresses match -- was tried to break the store -> read -> FMA -> store chain: 10.3 ms against
             // 9.7, and not sufficient as it stood: a run of equal destinations as long as the group's tile count wraps and puts
-            // the same destination at place p + 1 of tile t and place p of tile t + 1.  The launch is bound by LDS traffic and
-            // the producers' split, not by this chain: DESIGN.md 4.7.)
+            // the same destination at place p + 1 of tile t and place p of tile t + 1.)
             auto consume = [&](auto nrt_c) {
                 constexpr int NRT = decltype(nrt_c)::value;
                 constexpr int LA = RGCN_P3_LA;
                 Ops o[NRT];
-                f32x4 y[NRT], old[NRT];
+                f32x4 y[NRT][NCT], old[NRT][NCT];
                 float* dst[NRT];
 #pragma unroll
                 for (int t = 0; t < LA; ++t)
@@ -416,42 +453,51 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
                 for (int step = 0; step <= NRT; ++step) {
                     if (step < NRT) {
                         if (step + LA < NRT) load_ops(o[step + LA], step + LA);
-                        y[step] = mfma_half(o[step], f32x4{0.f, 0.f, 0.f, 0.f}, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) y[step][ct] = mfma_half(o[step], f32x4{0.f, 0.f, 0.f, 0.f}, 0, ct);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // one group of vector instructions per tile: store of tile step - 1, then address + accumulator read of
                     // tile step (in this order: consecutive tiles may scatter into the same accumulator row)
                     if (RGCN_P3_ABL & 4) {
-                        if (step >= 1) asm volatile("" ::"v"(y[step - 1]), "v"(o[step - 1].w1), "v"(o[step - 1].d1));
-                        if (step < NRT) old[step] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (step >= 1) asm volatile("" ::"v"(y[step - 1][0]), "v"(y[step - 1][NCT - 1]), "v"(o[step - 1].w1), "v"(o[step - 1].d1));
+                        if (step < NRT)
+#pragma unroll
+                            for (int ct = 0; ct < NCT; ++ct) old[step][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
                     } else if (step >= 1) {
-                        *(f32x4*)dst[step - 1] = y[step - 1] * o[step - 1].w1 + old[step - 1];
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+                            *(f32x4*)(dst[step - 1] + 16 * ct) = y[step - 1][ct] * o[step - 1].w1 + old[step - 1][ct];
                     }
                     if (step < NRT && !(RGCN_P3_ABL & 4)) {
                         // (RGCN_P3_ABL & 64, timing only, wrong results: the 16 lanes of a phase address rows that differ mod
                         // 16 -- what a conflict-free accumulator order could buy)
                         dst[step] = acc_ptr((RGCN_P3_ABL & 64) ? ((o[step].d1 & 0xFFFFF0) | rowl) : o[step].d1, col4_bytes);
-                        old[step] = *(const f32x4*)dst[step];
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) old[step][ct] = *(const f32x4*)(dst[step] + 16 * ct);
                     }
                     if (step < NRT) {
                         __builtin_amdgcn_sched_barrier(0);
-                        y[step] = mfma_half(o[step], y[step], 1);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) y[step][ct] = mfma_half(o[step], y[step][ct], 1, ct);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             };
-            // ---- chunks with a repeated destination in some row tile: tile by tile; a flagged tile takes the Y orientation
-            // and the run-sum product Z = P Y + old in exact fp32 (rgcn_tile_kernel stage B)
-            auto process_slow = [&](int t) {
+            // ---- tile by tile: chunks with a repeated destination in some row tile (a flagged tile takes the Y orientation
+            // and the run-sum product Z = P Y + old in exact fp32, rgcn_tile_kernel stage B), and serial chunks
+            auto process_slow = [&](int t, bool dup) {
                 Ops o;
                 load_ops(o, t);
-                const bool dup = (flags >> t) & 1;
                 if (!dup) {
                     float* d = acc_ptr(o.d1, col4_bytes);
-                    const f32x4 oldv = *(const f32x4*)d;
-                    f32x4 yv = mfma_half(o, f32x4{0.f, 0.f, 0.f, 0.f}, 0);
-                    yv = mfma_half(o, yv, 1);
-                    *(f32x4*)d = yv * o.w1 + oldv;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const f32x4 oldv = *(const f32x4*)(d + 16 * ct);
+                        f32x4 yv = mfma_half(o, f32x4{0.f, 0.f, 0.f, 0.f}, 0, ct);
+                        yv = mfma_half(o, yv, 1, ct);
+                        *(f32x4*)(d + 16 * ct) = yv * o.w1 + oldv;
+                    }
                     return;
                 }
                 f32x4 w4;
@@ -462,71 +508,77 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
                     w4[i] = __int_as_float(wd.x);
                     d4[i] = wd.y;
                 }
-                f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-                        yv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.pl[px[q]][s], __builtin_bit_cast(bf16x8, wcur[pwl[q]][s]), yv, 0, 0, 0);
-                float* d[4];
                 float pm[4];
-                f32x4 oldv;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    d[i] = acc_ptr(d4[i], col1_bytes);
-                    pm[i] = ((unsigned)d4[i] >> 24) == (unsigned)rowl ? w4[i] : 0.f;
-                    oldv[i] = *d[i];
+                for (int i = 0; i < 4; ++i) pm[i] = ((unsigned)d4[i] >> 24) == (unsigned)rowl ? w4[i] : 0.f;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            yv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.pl[px[q]][s], __builtin_bit_cast(bf16x8, wcur[ct][pwl[q]][s]), yv, 0, 0, 0);
+                    float* d[4];
+                    f32x4 oldv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        d[i] = acc_ptr(d4[i], col1_bytes) + 16 * ct;
+                        oldv[i] = *d[i];
+                    }
+                    f32x4 z1 = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], yv[0], oldv, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], yv[1], z1, 0, 0, 0);
+                    z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], yv[2], z0, 0, 0, 0);
+                    z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], yv[3], z1, 0, 0, 0);
+                    const f32x4 v = z0 + z1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *d[i] = v[i];
                 }
-                f32x4 z1 = {0.f, 0.f, 0.f, 0.f};
-                f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[0], yv[0], oldv, 0, 0, 0);
-                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[1], yv[1], z1, 0, 0, 0);
-                z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[2], yv[2], z0, 0, 0, 0);
-                z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[3], yv[3], z1, 0, 0, 0);
-                const f32x4 v = z0 + z1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *d[i] = v[i];
             };
             using std::integral_constant;
-            if (flags == 0) {
-                switch (nrt) {
+            if (flags == 0 && !serial) {
+                switch (n) {
                     case 1: consume(integral_constant<int, 1>{}); break;
                     case 2: consume(integral_constant<int, 2>{}); break;
                     case 3: consume(integral_constant<int, 3>{}); break;
                     case 4: consume(integral_constant<int, 4>{}); break;
-                    case 5: consume(integral_constant<int, 5>{}); break;
-                    case 6: consume(integral_constant<int, 6>{}); break;
-                    case 7: consume(integral_constant<int, 7>{}); break;
-                    case 8: consume(integral_constant<int, 8>{}); break;
+                    case 5: if constexpr (TEAMS == 1) consume(integral_constant<int, 5>{}); break;
+                    case 6: if constexpr (TEAMS == 1) consume(integral_constant<int, 6>{}); break;
+                    case 7: if constexpr (TEAMS == 1) consume(integral_constant<int, 7>{}); break;
+                    case 8: if constexpr (TEAMS == 1) consume(integral_constant<int, 8>{}); break;
                     default: break;
                 }
             } else {
-                for (int t = 0; t < nrt; ++t) process_slow(t);
+                for (int t = 0; t < n; ++t) process_slow(t, (flags >> t) & 1);
             }
-            P3S(t2);
+            P3S(t2s);
             if (swap_b) {
                 wait_vmcnt<0>();                     // the asm prefetch (this wave's only vector-memory traffic)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    wcur[pl][0] = wnext[pl][0];
-                    wcur[pl][1] = wnext[pl][1];
-                }
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        wcur[ct][pl][0] = wnext[ct][pl][0];
+                        wcur[ct][pl][1] = wnext[ct][pl][1];
+                    }
             }
             rel_cur = rel_next;
             pending = it + 2 < nch && rel_next2 != rel_next;
             if (pending) prefetch_rel(rel_next2);
-            P3S(t3);
+            P3S(t3s);
             wg_barrier();
             if (it + 1 == tend && it + 1 < nch) {
-                // this chunk closed a tile: the 256 consumer threads store it and reset the accumulator; the producers wait at
+                // this chunk closed a tile: the consumer threads store it and reset the accumulator; the producers wait at
                 // the same extra barrier with the next tile's first chunks already in LDS / in flight
-                tile_epilogue<LDO, true>(a, out_lds, tile_cur, tid - 256, 256);
+                tile_epilogue<LDO, true>(a, out_lds, tile_cur, tid - 256, 64 * kConsumers);
                 ++tile_cur;
                 tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the epilogue's memory operations here, once per tile
                 wg_barrier();
             }
-            P3S(t4);
-            P3A(sc_meta, t0, t1); P3A(sc_comp, t1, t2); P3A(sc_swap, t2, t3); P3A(sc_bar, t3, t4);
+            P3S(t4s);
+            P3A(sc_meta, t0s, t1s); P3A(sc_comp, t1s, t2s); P3A(sc_swap, t2s, t3s); P3A(sc_bar, t3s, t4s);
         }
 #ifdef RGCN_P3_STAMPS
         if (g_p3_stamps && cw == 0 && lane == 0) {
@@ -537,7 +589,7 @@ __global__ void __launch_bounds__(kP3Threads, 2) rgcn_tile3p_kernel(const TileAr
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the consumers is pending when the producer code follows
     }
     if (wave < 4) p3_producer_loop(a, ring, wring, dring, c0, nch, lane, wave, tile0);
-    tile_epilogue<LDO, false>(a, out_lds, tile1 - 1, tid, kP3Threads);
+    tile_epilogue<LDO, false>(a, out_lds, tile1 - 1, tid, kThreadsAll);
 }
 
 // bytes of dynamic LDS at tile size `tile`
@@ -545,29 +597,42 @@ static size_t p3_lds_bytes(int tile) {
     return sizeof(float) * (size_t)(tile + 1) * kP3LDO + 2 * (size_t)kP3SlotBytes + 2 * kP3CH * 8;
 }
 
-// Launch (called by run_tile in rgcn_kernels.hip when RGCN_FLAG_SPLIT_PRODUCERS is set and the shapes fit): `a.wp` points at
-// the bf16 planes of the packed weights.  Returns RGCN_ERR_LDS / RGCN_ERR_PLAN when it does not apply.
-int launch_tile3p(const TileArgs& a, int n_tiles, void* stream) {
-    if (a.x_bytes == 0) return RGCN_ERR_PLAN;          // buffer-descriptor addressing only
-    const size_t lds = p3_lds_bytes(a.tile);
-    if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
+// Launch (called by run_tile in rgcn_tile_fp32.hip when RGCN_FLAG_SPLIT_PRODUCERS is set and the shapes fit): `a.wp` points at
+// the bf16 planes of the packed weights.  Layout-1 plans run the two-team form, layout-0 plans the one-team form.
+// Returns RGCN_ERR_LDS / RGCN_ERR_PLAN when it does not apply.
+#ifndef RGCN_P3_NCT          // 16-column tiles per consumer wave of the two-team form (1: 8 consumer waves, 2: 4)
+#define RGCN_P3_NCT 1
+#endif
+#ifndef RGCN_P3_TEAMS        // experiment knob: 1 runs layout-1 plans on the one-team kernel (any placement is valid for it)
+#define RGCN_P3_TEAMS 2
+#endif
+template <int TEAMS, int NCT>
+static int launch_tile3p_as(const TileArgs& b, int nwg, size_t lds, hipStream_t stream) {
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute((const void*)rgcn_tile3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        e = hipFuncSetAttribute((const void*)rgcn_tile3p_kernel<TEAMS, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int)e;
         done.fetch_or(bit, std::memory_order_release);
     }
+    hipLaunchKernelGGL((rgcn_tile3p_kernel<TEAMS, NCT>), dim3(nwg), dim3(P3Cfg<TEAMS, NCT>::kThreads), lds, stream, b);
+    return (int)hipGetLastError();
+}
+
+int launch_tile3p(const TileArgs& a, int n_tiles, int layout, void* stream) {
+    if (a.x_bytes == 0) return RGCN_ERR_PLAN;          // buffer-descriptor addressing only
+    const size_t lds = p3_lds_bytes(a.tile);
+    if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
     // walking several tiles pays once every CU gets many workgroups either way (start-up: two trips to memory per workgroup);
     // on graphs of a few launch rounds one tile per workgroup balances better (300k nodes / 1,340 tiles: 4.28 against 4.44 ms)
     TileArgs b = a;
     if (n_tiles < 16 * 256) b.tiles_per_wg = 1;
     const int nwg = (n_tiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
-    hipLaunchKernelGGL(rgcn_tile3p_kernel, dim3(nwg), dim3(kP3Threads), lds, (hipStream_t)stream, b);
-    return (int)hipGetLastError();
+    if (layout == 1 && RGCN_P3_TEAMS == 2) return launch_tile3p_as<2, RGCN_P3_NCT>(b, nwg, lds, (hipStream_t)stream);
+    return launch_tile3p_as<1, 1>(b, nwg, lds, (hipStream_t)stream);
 }
 
 #ifdef RGCN_P3_STAMPS

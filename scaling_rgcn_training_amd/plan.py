@@ -66,7 +66,7 @@ class TilePlan:
                           #   None for plans built on the device
     slot_row: Tensor      # int32 [n_chunks * chunk]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
     slot_acc: Tensor      # int32 [n_chunks * chunk]  run-end position << 24 | accumulator row
-    layout: int = 0       # 0: rows of a group dealt over all its row tiles; 1: split placement (split_placement)
+    layout: int = 0       # 0: rows of a group dealt over all its row tiles; 1: team placement (team_placement)
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -109,12 +109,12 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
 
     gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src).
     chunk: edge slots per chunk (one of CHUNKS).
-    split: the SPLIT placement (layout 1, 128-slot chunks only), see ``split_placement``.
+    split: the TEAM placement (layout 1, 128-slot chunks only), see ``team_placement``.
     """
     if chunk not in CHUNKS:
         raise ValueError(f"chunk must be one of {CHUNKS}")
     if split and chunk != 128:
-        raise ValueError("the split placement needs 128-slot chunks")
+        raise ValueError("the team placement needs 128-slot chunks")
     CHUNK = chunk  # noqa: N806  (shadows the module default inside this function)
     if node_end is None:
         node_end = n_nodes
@@ -183,7 +183,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
         # slots of the chunk's used row tiles (a multiple of 16; padding sits at the end of every tile)
         chunk_cnt = (torch.clamp(gnt[grp_of_chunk] - idx_in_grp * (CHUNK // g16), max=CHUNK // g16) * g16).to(torch.int32)
     else:
-        slot, chunk_cnt, straddle = split_placement(dstl, gcnt, grp_of_edge, rank, chunk_base, grp_of_chunk, idx_in_grp)
+        slot, chunk_cnt, straddle = team_placement(dstl, gcnt, grp_of_edge, rank, chunk_base, grp_of_chunk, idx_in_grp)
     n_slots = n_chunks * CHUNK
     slot_src = torch.full((n_slots,), n_nodes, dtype=torch.int32, device=dev)  # padding: one past the last row
     slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
@@ -222,32 +222,36 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     layout=1 if split else 0)
 
 
-def split_placement(dstl: Tensor, gcnt: Tensor, grp_of_edge: Tensor, rank: Tensor, chunk_base: Tensor,
-                    grp_of_chunk: Tensor, idx_in_grp: Tensor):
-    """Layout 1 (128-slot chunks): chunk c of a group takes the group's sorted rows [128 c, 128 c + 128) -- n_c of them.
-    With n_c > 64 the rows are cut at a RUN BOUNDARY s (the destination changes between rows s - 1 and s) into two parts
-    of at most 64 rows: part 0 is dealt over row tiles 0..3 of the chunk (row j -> tile j mod 4, place j div 4), part 1 over
-    tiles 4 .. 4 + nt1 - 1, nt1 = ceil((n_c - s) / 16).  So the two 64-slot halves of a chunk hold DISJOINT destination
-    sets and can be accumulated by different waves at the same time (the bf16x3 forward / dX kernel: a wave pair per
-    half).  s is the boundary closest to ceil(n_c / 2) inside [n_c - 64, 64], the lower one on a tie; a chunk without
-    one (a single destination's run covers the window) is cut at the middle and flagged (chunk_flags bit 8: the halves
-    share a destination).  n_c <= 64: all rows in part 0, dealt over ceil(n_c / 16) tiles as in layout 0.
-    The used row tiles of a chunk stay contiguous from tile 0, so chunk_cnt keeps its meaning for every kernel.
+def team_placement(dstl: Tensor, gcnt: Tensor, grp_of_edge: Tensor, rank: Tensor, chunk_base: Tensor,
+                   grp_of_chunk: Tensor, idx_in_grp: Tensor):
+    """Layout 1 (128-slot chunks): chunk c of a group takes the group's sorted rows [128 c, 128 c + 128) -- n_c of them, on
+    nt = ceil(n_c / 16) row tiles.  The rows are cut at a RUN BOUNDARY s (the destination changes between rows s - 1 and s)
+    into part A = rows [0, s) on the chunk's first nA = ceil(nt / 2) row tiles and part B = rows [s, n_c) on the other
+    nB = nt - nA (row j of a part -> the part's tile j mod n_part, place j div n_part).  So the two parts of a chunk hold
+    DISJOINT destination sets, and two teams of consumer waves of the forward / dX kernel (csrc/rgcn_tile3p.hip) accumulate
+    them at the same time without ever touching the same accumulator row.  s lies in [max(1, n_c - 16 nB), min(n_c - 1,
+    16 nA)] -- both parts fit their tiles and need all of them, so a chunk takes exactly the nt row tiles of layout 0 --
+    and is the boundary closest to the middle of that window (the lower one on a tie); a chunk without one (a single
+    destination's run covers the window) is cut at the middle and flagged (chunk_flags bit 8: the parts share a destination,
+    one team takes the whole chunk).  nt = 1: everything in part A.
     Returns (slot of every row, chunk_cnt, straddle flag per chunk)."""
     C, g16 = 128, ROWS_PER_MFMA_TILE
     dev = dstl.device
     n_chunks = int(grp_of_chunk.shape[0])
-    n_c_chunk = torch.clamp(gcnt[grp_of_chunk] - idx_in_grp * C, max=C)
-    big_c = n_c_chunk > 64
-    mid_c = (n_c_chunk + 1) // 2
-    lo_c = torch.clamp(n_c_chunk - 64, min=1)
-    hi_c = torch.clamp(n_c_chunk - 1, max=64)
+    n_c = torch.clamp(gcnt[grp_of_chunk] - idx_in_grp * C, max=C)
+    nt = (n_c + (g16 - 1)) // g16
+    n_a = (nt + 1) // 2
+    n_b = nt - n_a
+    two = nt > 1
+    lo_c = torch.clamp(n_c - g16 * n_b, min=1)
+    hi_c = torch.minimum(n_c - 1, g16 * n_a)
+    mid_c = (lo_c + hi_c + 1) // 2
     cidx = rank // C
     jc = rank - cidx * C
     chunk_of_row = chunk_base[grp_of_edge] + cidx
     prev_dstl = torch.cat([dstl[:1], dstl[:-1]])
     boundary = (jc >= 1) & (dstl != prev_dstl)             # jc >= 1: row jc - 1 belongs to the same chunk range
-    cand = boundary & big_c[chunk_of_row] & (jc >= lo_c[chunk_of_row]) & (jc <= hi_c[chunk_of_row])
+    cand = boundary & two[chunk_of_row] & (jc >= lo_c[chunk_of_row]) & (jc <= hi_c[chunk_of_row])
     dist = jc - mid_c[chunk_of_row]
     score = 2 * dist.abs() + (dist > 0).to(torch.int64)    # mid, mid - 1, mid + 1, mid - 2, ...
     big_score = 1 << 20
@@ -256,16 +260,13 @@ def split_placement(dstl: Tensor, gcnt: Tensor, grp_of_edge: Tensor, rank: Tenso
     has = best < big_score
     k = best // 2
     s_found = torch.where(best % 2 == 1, mid_c + k, mid_c - k)
-    s_c = torch.where(has, s_found, torch.minimum(torch.maximum(mid_c, lo_c), hi_c))
-    straddle = big_c & ~has
-    nt1_c = (n_c_chunk - s_c + (g16 - 1)) // g16
-    nts_c = (n_c_chunk + (g16 - 1)) // g16
-    chunk_cnt = torch.where(big_c, (4 + nt1_c) * g16, nts_c * g16).to(torch.int32)
-    s_r, big_r = s_c[chunk_of_row], big_c[chunk_of_row]
-    nts_r, nt1_r = nts_c[chunk_of_row], torch.clamp(nt1_c[chunk_of_row], min=1)
+    s_c = torch.where(two, torch.where(has, s_found, mid_c), n_c)
+    straddle = two & ~has
+    chunk_cnt = (nt * g16).to(torch.int32)
+    s_r = s_c[chunk_of_row]
+    na_r, nb_r = n_a[chunk_of_row], torch.clamp(n_b[chunk_of_row], min=1)
     j1 = torch.clamp(jc - s_r, min=0)
-    in_chunk = torch.where(~big_r, (jc % nts_r) * g16 + jc // nts_r,
-                           torch.where(jc < s_r, (jc % 4) * g16 + jc // 4, 64 + (j1 % nt1_r) * g16 + j1 // nt1_r))
+    in_chunk = torch.where(jc < s_r, (jc % na_r) * g16 + jc // na_r, (na_r + j1 % nb_r) * g16 + j1 // nb_r)
     return chunk_of_row * C + in_chunk, chunk_cnt, straddle
 
 

@@ -125,20 +125,37 @@ class Trainer:
             print("weight transfer done")
 
     def _device_data(self, graph):
-        """``graph.training_data`` on the training device, moved ONCE per (graph, device): the layer's graph plans are
-        cached on the identity of the edge tensors, so a fresh copy per call (what ``Data.to`` returns) would rebuild
-        them for the final test evaluation and keep the old copies alive."""
-        cached = getattr(graph, "_device_data", None)
-        if cached is None or cached[0] != self.device or cached[1] is not graph.training_data:
-            cached = (self.device, graph.training_data, graph.training_data.to(self.device))
+        """``graph.training_data`` on the training device.  Only the EDGE tensors are cached on the graph (keyed on the
+        identity and version of the host tensors): the layer's graph plans are cached on the identity of the device edge
+        tensors, so a fresh copy per call (what ``Data.to`` returns) would rebuild them for every ``train`` and for the final
+        test evaluation.  Everything else -- labels, split indices, whatever a caller assigned since the last call
+        (graphs/dataset.py:30-35,53-54) -- is moved afresh on every call, as the reference's ``.to(device)`` does
+        (model/modelTrainer.py:43)."""
+        data = graph.training_data
+        key = (self.device, id(data.edge_index), data.edge_index._version, id(data.edge_type), data.edge_type._version)
+        cached = getattr(graph, "_device_edges", None)
+        if cached is None or cached[0] != key:
+            cached = (key, data.edge_index.to(self.device), data.edge_type.to(self.device), data.edge_index, data.edge_type)
             try:
-                graph._device_data = cached
+                graph._device_edges = cached
             except AttributeError:
                 pass
-        return cached[2]
+        out = type(data)()
+        for k, v in data.__dict__.items():
+            if k == "edge_index":
+                v = cached[1]
+            elif k == "edge_type":
+                v = cached[2]
+            elif torch.is_tensor(v):
+                v = v.to(self.device)
+            setattr(out, k, v)
+        return out
 
-    def _want_hipgraph(self, training_data) -> bool:
+    def _want_hipgraph(self, training_data, model: nn.Module = None) -> bool:
         if self.device.type != "cuda" or not self.eval_no_grad:
+            return False
+        # edge-partitioned layers issue asynchronous RCCL collectives and wait on their handles: not captured
+        if model is not None and any(getattr(m, "dist", None) is not None for m in model.modules()):
             return False
         if self.hipgraph == "auto":
             return int(training_data.edge_type.shape[0]) <= self.HIPGRAPH_AUTO_MAX_EDGES
@@ -149,7 +166,7 @@ class Trainer:
         model = model.to(self.device)
         training_data = self._device_data(graph)
         targets = training_data.y_train.to(torch.float32)
-        if self._want_hipgraph(training_data):
+        if self._want_hipgraph(training_data, model):
             try:
                 out = self._train_hipgraph(model, training_data, targets, loss_f, activation, sum_graph)
                 self.last_train_mode = "hipgraph"
@@ -195,6 +212,13 @@ class Trainer:
         dev = self.device
         params = [q for q in model.parameters()]
         saved = [q.detach().clone() for q in params]
+        # the warm-up epoch also advances what is not a parameter: module buffers and the device's RNG stream (the attention
+        # model's dropout) -- both are put back, so that the captured loop starts where an eager ``train`` starts.  (Inside
+        # the replayed graphs the dropout masks come from torch's graph-safe Philox offsets: same distribution as the eager
+        # loop's, not the same stream -- loss curves of Emb_ATT_Layers with dropout agree statistically, not bit for bit.)
+        buffers = [b for b in model.buffers()]
+        saved_buffers = [b.detach().clone() for b in buffers]
+        rng_state = torch.cuda.get_rng_state(dev)
         optimizer = torch.optim.Adam(params, lr=self.lr, weight_decay=self.weight_d, capturable=True)
         idx_train = training_data.x_train.to(dev)
 
@@ -224,10 +248,13 @@ class Trainer:
                 with torch.no_grad():
                     for q, q0 in zip(params, saved):
                         q.copy_(q0)
+                    for b, b0 in zip(buffers, saved_buffers):
+                        b.copy_(b0)
                     for st in optimizer.state.values():
                         for v in st.values():
                             if torch.is_tensor(v):
                                 v.zero_()
+                torch.cuda.set_rng_state(rng_state, dev)
                 optimizer.zero_grad(set_to_none=True)
                 g_eval = g_train = pred = loss = None
                 if not sum_graph:

@@ -374,30 +374,6 @@ def test_fused_activation_standalone_relu_backward(dev):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,e,r,tile,skew", [(3000, 330000, 3, 352, False), (2000, 200000, 4, 128, True), (5000, 90000, 7, 352, False),
-                                             (800, 120000, 2, 64, True)])
-def test_split_precision_kernel_matches_oracle(dev, n, e, r, tile, skew):
-    """The bf16 x 3 forward / dX kernel (64 x 64, layout-1 plans: groups of 100+ edges so that chunks fill both halves,
-    hubs so that some chunks' halves share a destination -- flag 256 -- and row tiles repeat destinations) against the float64
-    oracle under both bounds of oracle/tolerance.py, and against the exact-fp32 kernel on the same plan."""
-    from scaling_rgcn_training_amd import _lib
-    din = dout = 64
-    ei, et = O.synthetic_graph(n, e, r, seed=n + r, skew=skew)
-    ei[:, 100:160] = ei[:, 20:80]           # duplicate triples
-    et[100:160] = et[20:80]
-    w, root, bias = O.synthetic_params(r, din, dout, seed=9)
-    g = torch.Generator().manual_seed(17)
-    bias = torch.randn(dout, generator=g) * 0.1
-    x = torch.randn(n, din, generator=g)
-    dg = torch.randn(n, dout, generator=g)
-    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
-    res3 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, split=True)
-    _check_layer(res3, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [bf16x3 T{tile} n{n}]")
-    res1 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, split=True, flags=_lib.FLAG_EXACT_FP32)
-    _check_layer(res1, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [fp32 on layout 1 T{tile} n{n}]")
-    # the two kernels agree far inside the tolerance (different summation orders, same 24-bit operands)
-    for a, b in zip(res3[:2], res1[:2]):
-        assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, float(np.abs(b).max()))
     assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel
 
 
@@ -475,13 +451,17 @@ def test_dw_root_streaming_kernel(dev, rows, din, dout):
     assert torch.equal(dr, dr2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("teams", [False, True], ids=["layout0-one-team", "layout1-two-teams"])
 @pytest.mark.parametrize("n,e,r,tile,skew", [(3000, 330000, 3, 224, False), (2000, 200000, 4, 128, True), (5000, 90000, 7, 224, False),
-                                             (800, 120000, 2, 64, True), (40, 300, 2, 16, False)])
-def test_split_producers_kernel_matches_oracle(dev, n, e, r, tile, skew):
-    """The bf16 x 3 forward / dX kernel whose PRODUCER waves split the gathered rows (csrc/rgcn_tile3p.hip; 64 x 64, layout-0
-    plans, 128-slot chunks, tiles up to 224: hubs and duplicate triples so that row tiles repeat destinations and take its
-    run-sum path, chunks of 1 to 8 row tiles, a graph of three tiles) against the float64 oracle under both bounds of
-    oracle/tolerance.py, and against the exact-fp32 kernel on the same plan; bit-reproducible."""
+                                             (800, 120000, 2, 64, True), (40, 300, 2, 16, False), (3000, 60000, 40, 224, True)])
+def test_split_producers_kernel_matches_oracle(dev, n, e, r, tile, skew, teams):
+    """The bf16 x 3 forward / dX kernel whose PRODUCER waves split the gathered rows (csrc/rgcn_tile3p.hip; 64 x 64, 128-slot
+    chunks, tiles up to 224) in both of its forms -- layout-0 plans: one team of consumer waves; layout-1 plans
+    (plan.team_placement): two teams on the destination-disjoint parts of every chunk.  Hubs and duplicate triples so that
+    row tiles repeat destinations and take the run-sum path and some chunks' parts share a destination (flag 256: one team
+    takes the chunk), chunks of 1 to 8 row tiles (one-tile chunks leave team B idle), a graph of three tiles.  Against the
+    float64 oracle under both bounds of oracle/tolerance.py, and against the exact-fp32 kernel on the same plan;
+    bit-reproducible."""
     from scaling_rgcn_training_amd import _lib
     din = dout = 64
     ei, et = O.synthetic_graph(n, e, r, seed=n + r, skew=skew)
@@ -493,13 +473,15 @@ def test_split_producers_kernel_matches_oracle(dev, n, e, r, tile, skew):
     x = torch.randn(n, din, generator=g)
     dg = torch.randn(n, dout, generator=g)
     ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
-    res3 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS)
-    _check_layer(res3, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [bf16x3 producers T{tile} n{n}]")
-    res1 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128)
+    res3 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS, split=teams)
+    _check_layer(res3, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [bf16x3 producers T{tile} n{n} layout {int(teams)}]")
+    res1 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, split=teams)      # exact-fp32 kernels, same plan
+    if teams:
+        _check_layer(res1, ref, gr, x, ei, et, w, root, bias, dg, tag=f" [fp32 on layout 1 T{tile} n{n}]")
     for a, b in zip(res3[:2], res1[:2]):
         assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, float(np.abs(b).max()))
     assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel
-    again = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS)
+    again = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS, split=teams)
     assert np.array_equal(res3[0], again[0]) and np.array_equal(res3[1], again[1])
 
 
@@ -524,6 +506,7 @@ def test_split_producers_through_the_module(dev):
         out = conv(xd, eid, etd, _input_relu=True)
         out.backward(dg.to(dev))
         assert conv._plans(xd, eid, etd).fwd.tile <= (224 if on else 352)
+        assert conv._plans(xd, eid, etd).fwd.layout == int(on)       # the two-team form of the kernel runs on team-placement plans
         with torch.no_grad():
             act = conv(xd, eid, etd, _activation="relu")
         outs.append([t.detach().cpu().numpy() for t in (out, xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad, act)])
@@ -568,6 +551,49 @@ def test_tile_major_dw_through_the_module(dev, monkeypatch, split):
     assert_close(conv.root.grad.cpu().numpy(), gr["root"], c["root"], f"module d_root (side stream) [{split}]", cpu32=g32["root"])
     assert_close(conv.bias.grad.cpu().numpy(), gr["bias"], c["bias"], f"module d_bias (side stream) [{split}]", cpu32=g32["bias"])
     assert torch.all(conv.weight.grad[r - 1] == 0)
+
+
+def test_tile_major_dw_falls_back_when_not_buffer_addressable(dev, monkeypatch):
+    """rgcn_bwd_dw_tiles gathers through buffer descriptors only (< 2^24 rows, < 4 GiB); on larger operands
+    the library answers RGCN_ERR_ADDRESS and the module must not plan for that kernel -- its backward then runs the relation-
+    major kernels (64-bit pointer gathers) and still matches the oracle.  The size limit is faked (a 16.7M-node graph does not
+    fit a test): RGCN_FLAG_POINTER_GATHER for the raw call, ``_lib.buffer_addressable`` patched for the module."""
+    from scaling_rgcn_training_amd import _lib, conv as C, plan as P
+    monkeypatch.setattr(C, "DW_TILES_MIN_EDGES", 1)
+    n, e, r = 5000, 100000, 6
+    ei, et = O.synthetic_graph(n, e, r, seed=2)
+    w, root, bias = O.synthetic_params(r, 64, 64, seed=2)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, 64, generator=g)
+    dg = torch.randn(n, 64, generator=g)
+    eid, etd = ei.to(dev), et.to(dev)
+    # the raw entry point: a distinct status, not "inconsistent graph plan"
+    plans = P.build_graph_plans_device(eid, etd, n, r, 224, chunk=128, dw_tiles=True)
+    dw = torch.empty(r, 64, 64, device=dev)
+    with pytest.raises(_lib.RgcnLibraryError) as err:
+        _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, x.to(dev), 64, dg.to(dev), 64, dw, _lib.FLAG_POINTER_GATHER)
+    assert err.value.status == _lib.ERR_ADDRESS and "buffer descriptor" in str(err.value)
+    P.clear_plan_cache()
+    # the module: no tile-major plan, relation-major backward
+    monkeypatch.setattr(_lib, "buffer_addressable", lambda rows, ld: False)
+    conv = C.RGCNConv(64, 64, r).to(dev)
+    conv.kernel_flags = _lib.FLAG_POINTER_GATHER
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.root.copy_(root)
+        conv.bias.copy_(bias)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, eid, etd)
+    assert conv._plans(xd, eid, etd).dw is None
+    out.backward(dg.to(dev))
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
+    _, g32 = cpu32_reference(x, ei, et, w, root, bias, dg)
+    assert_close(out.detach().cpu().numpy(), ref, c_out, "fallback out")
+    assert_close(xd.grad.cpu().numpy(), gr["x"], c["x"], "fallback d_x", cpu32=g32["x"])
+    assert_close(conv.weight.grad.cpu().numpy(), gr["weight"], c["weight"], "fallback d_weight", cpu32=g32["weight"])
+    assert_close(conv.root.grad.cpu().numpy(), gr["root"], c["root"], "fallback d_root", cpu32=g32["root"])
+    P.clear_plan_cache()
 
 
 @pytest.mark.parametrize("seed", range(5))

@@ -102,3 +102,30 @@ def test_choose_layout_respects_lds_and_amortises_chunks():
         for acc_w, ring_w in ((np_, kp), (kp, np_)):        # forward, dX
             assert (t + 1) * (acc_w + ACC_PAD) * 4 + 2 * c * (ring_w + 2) * 4 <= LDS_BYTES
     assert choose_layout(10_000_000, 100_000_000, 32, 64, 64) == (352, 128)
+
+
+def test_trainer_device_data_caches_edges_only():
+    """``Trainer._device_data`` keeps only the edge tensors on the device between calls (the plan cache keys on
+    their identity); labels and split indices assigned after a first ``train`` (a new fold: graphs/dataset.py:30-35) must be
+    what the next call sees."""
+    from scaling_rgcn_training_amd.data import Data
+    from scaling_rgcn_training_amd.trainer import Trainer
+
+    class G:
+        pass
+
+    g = G()
+    g.training_data = Data(edge_index=torch.zeros(2, 5, dtype=torch.long), edge_type=torch.zeros(5, dtype=torch.long))
+    g.training_data.x_train = torch.tensor([0, 1])
+    g.training_data.y_train = torch.tensor([[1.0], [0.0]])
+    tr = Trainer(None, 4, 1, 4, 0.01, 0.0, verbose=False)
+    tr.device = torch.device("cpu")
+    a = tr._device_data(g)
+    g.training_data.x_train = torch.tensor([2, 3])              # re-split on the same graph
+    g.training_data.y_train = torch.tensor([[0.0], [1.0]])
+    b = tr._device_data(g)
+    assert b.edge_index is a.edge_index and b.edge_type is a.edge_type        # same device edge tensors: plans stay cached
+    assert torch.equal(b.x_train, torch.tensor([2, 3])) and torch.equal(b.y_train, torch.tensor([[0.0], [1.0]]))
+    g.training_data.edge_type = torch.ones(5, dtype=torch.long)               # a different graph tensor: moved again
+    c = tr._device_data(g)
+    assert torch.equal(c.edge_type, torch.ones(5, dtype=torch.long))

@@ -33,8 +33,7 @@ def _check_invariants(plan, n_real_edges):
     assert torch.all(cnt % 16 == 0) and torch.all(cnt >= 16) and torch.all(cnt <= c)
     used = (torch.arange(c // 16)[None, :] * 16 < cnt[:, None]).reshape(-1)   # row tiles inside chunk_cnt
     assert torch.all(nvalid[~used] == 0)
-    if plan.layout == 0:                                            # (layout 1: part 0 always spans four row tiles)
-        assert torch.all(nvalid[used] > 0)
+    assert torch.all(nvalid[used] > 0)
     assert int(nvalid.sum()) == n_real_edges + plan.n_owned         # + one root pseudo edge per node
     col = torch.arange(c)[None, :]
     dl = plan.slot_dstl.view(-1, 16)
@@ -255,33 +254,42 @@ def test_dw_walk_interleave():
     assert torch.equal(interleave_walk(units[:40], rel[:40], r1, walkers=2048, mode="rr"), units[:40])
 
 
-@pytest.mark.parametrize("tile", [64, 352])
-def test_split_placement_walks_and_keeps_halves_disjoint(golden, tile):
-    """Layout 1 (plan.split_placement): same multiset of slots and the same sums as layout 0 (the emulated walk of
-    every kernel still reproduces the golden results), the used row tiles of a chunk stay contiguous from tile 0, and the
-    two 64-slot halves of a chunk hold disjoint destinations unless chunk_flags bit 8 says otherwise."""
+@pytest.mark.parametrize("tile", [64, 224, 352])
+def test_team_placement_walks_and_keeps_parts_disjoint(golden, tile):
+    """Layout 1 (plan.team_placement): same multiset of slots and the same sums as layout 0 (the emulated walk of every
+    kernel still reproduces the golden results), a chunk takes exactly the ceil(rows / 16) row tiles of layout 0, every one
+    of them non-empty, and part A (the first ceil(nt / 2) row tiles) and part B (the others) hold disjoint destinations
+    unless chunk_flags bit 8 says otherwise -- what lets two consumer teams of rgcn_tile3p_kernel accumulate them at once."""
     if str(golden["mode"]) != "full":
         pytest.skip("plan is weight-mode independent")
     f = lambda k: torch.from_numpy(golden[k])
     n, r = int(golden["num_nodes"]), int(golden["num_relations"])
-    plans = P.build_graph_plans_torch(f("edge_index").long(), f("edge_type").long(), n, r, tile, chunk=128, split=True)
+    ei, et = f("edge_index").long(), f("edge_type").long()
+    plans = P.build_graph_plans_torch(ei, et, n, r, tile, chunk=128, split=True)
+    base = P.build_graph_plans_torch(ei, et, n, r, tile, chunk=128, split=False)
     e = _distinct(golden["edge_index"], golden["edge_type"], n, r)
-    for plan in (plans.fwd, plans.bwd):
+    for plan, plan0 in ((plans.fwd, base.fwd), (plans.bwd, base.bwd)):
         assert plan.layout == 1
         _check_invariants(plan, e)
-        dl = plan.slot_dstl.view(-1, 128).long()
-        cnt = plan.chunk_cnt.long()
+        assert plan.n_chunks == plan0.n_chunks and torch.equal(plan.chunk_rel, plan0.chunk_rel)
+        assert torch.equal(plan.tile_ptr, plan0.tile_ptr)
+        assert int(plan.chunk_cnt.sum()) == int(plan0.chunk_cnt.sum()), "the team placement costs no row tile"
+        dl = plan.slot_dstl.view(-1, 8, 16).long()
+        nt = (plan.chunk_cnt.long() // 16)
         fl = plan.chunk_flags.long()
-        used_tiles = (dl.view(-1, 8, 16) < plan.tile).any(2)                    # [chunks, 8]
-        want = torch.arange(8)[None, :] < (cnt // 16)[:, None]
-        assert not (used_tiles & ~want).any(), "no row outside tiles 0 .. cnt/16 - 1"
+        used_tiles = (dl < plan.tile).any(2)                    # [chunks, 8]
+        assert torch.equal(used_tiles, torch.arange(8)[None, :] < nt[:, None]), "row tiles 0 .. nt - 1, none of them empty"
+        n_straddle = 0
         for c in range(plan.n_chunks):
-            a = set(dl[c, :64][dl[c, :64] < plan.tile].tolist())
-            b = set(dl[c, 64:][dl[c, 64:] < plan.tile].tolist())
-            if a & b:
-                assert fl[c] & 256, f"chunk {c}: halves share destinations {sorted(a & b)[:4]} without the flag"
-            if b:
-                assert len(dl[c, :64][dl[c, :64] < plan.tile]) + len(dl[c, 64:][dl[c, 64:] < plan.tile]) > 64
+            na = (int(nt[c]) + 1) // 2
+            a = set(dl[c, :na][dl[c, :na] < plan.tile].tolist())
+            b = set(dl[c, na:][dl[c, na:] < plan.tile].tolist())
+            if fl[c] & 256:
+                n_straddle += 1
+                assert a & b, f"chunk {c}: flagged although its parts are disjoint"
+            else:
+                assert not (a & b), f"chunk {c}: parts share destinations {sorted(a & b)[:4]} without the flag"
+        assert n_straddle == 0 or n < 3000, "only the hub graphs (thousands of rows on a few destinations) have such chunks"
     w_all = np.concatenate([golden["weight"], golden["root"][None]], 0).astype(np.float64)
     out = emulate_spmm(plans.fwd, golden["x"], w_all, golden["bias"])
     np.testing.assert_allclose(out, golden["out"], rtol=1e-6, atol=1e-6)

@@ -17,10 +17,15 @@ def child():
     which = os.environ.get("VT_WHICH", "fwd,dx,dw").split(",")
     dev = torch.device("cuda:0")
     ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, r, 64, 64, dev)
+    if os.environ.get("VT_UNIQ") == "1":        # no two edges share (dst, relation): no run of equal destinations anywhere
+        key = torch.randperm(n * r, device=dev)[:e]
+        ei = torch.stack([ei[0], key // r])
+        et = key % r
+        del key
     tile, chunk = P.choose_layout(n, e, r, 64, 64)
     tile = int(os.environ.get("VT_TILE", tile))
     kflags = int(os.environ.get("VT_FLAGS", 0))
-    plans = P.build_graph_plans_device(ei, et, n, r, tile, chunk=chunk, dw_tiles="dw" in which)
+    plans = P.build_graph_plans_device(ei, et, n, r, tile, chunk=chunk, dw_tiles="dw" in which, split=os.environ.get("VT_SPLIT", "0") == "1")
     del ei, et
 
     def t(fn, reps=int(os.environ.get("VT_REPS", 12))):
