@@ -30,7 +30,8 @@ The JSON line also carries
                  and vice versa), timed on the same box right after the main run, + the element-wise differences of their results
   roofline_step  the whole step against HBM: algorithmic bytes of fwd + bwd (92.1 GB at the headline config) / ms_per_step
                  -- the number north_star's ">= 40 % of HBM roofline" refers to
-  ladder         GPU edges/s on the smaller rungs of SURVEY.md 8d ((100k, 1M), (1M, 10M), AIFB shape)
+  ladder         GPU edges/s on the smaller rungs of SURVEY.md 8d ((100k, 1M), (1M, 10M)) and on the shapes of the reference's
+                 datasets (AIFB, MUTAG, AM-like with basis decomposition), each with its plan's slot fill
   cpu_baseline   the oracle's PyG-loop restatement timed on this host's cores on the (1M, 10M) rung, beside the GPU
                  figure of the SAME rung (rank 0, N = 1 only).
 """
@@ -56,8 +57,12 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mf
 # cannot be read inside this process, so `roofline.traffic` quotes the newest committed pass and names it
 PMC_TRAFFIC_FILE = os.environ.get("RGCN_PMC_TRAFFIC_FILE", "r02_pmc_traffic.json")
 HEADLINE = (10_000_000, 100_000_000, 32, 64)
-LADDER = (("100k/1M", 100_000, 1_000_000, 32, 64, 64), ("1M/10M", 1_000_000, 10_000_000, 32, 64, 64),
-          ("AIFB shape 63->16", 8_243, 49_838, 89, 63, 16))
+# (name, nodes, edges, relations R', in, out, num_bases): the smaller rungs of SURVEY.md 8d and the shapes of the reference's
+# own datasets (model/modelTrainer.py:78,92: R' = 2R + 1 = 89 / 45 / ~267; MUTAG's edge count is a guess -- the file is not
+# shipped; AM: BASELINE.json configs[2], hidden 32, basis decomposition B = 30)
+LADDER = (("100k/1M", 100_000, 1_000_000, 32, 64, 64, None), ("1M/10M", 1_000_000, 10_000_000, 32, 64, 64, None),
+          ("AIFB shape 63->16", 8_243, 49_838, 89, 63, 16, None), ("MUTAG shape 63->16", 23_644, 148_000, 45, 63, 16, None),
+          ("AM-like 32->32 B=30", 1_500_000, 6_000_000, 267, 32, 32, 30))
 CPU_RUNG = ("1M/10M", 1_000_000, 10_000_000)
 
 
@@ -79,10 +84,18 @@ def algorithmic_flops(e, n, r, din, dout):
     return {"fwd": fwd, "dx": 2.0 * din * dout * (s_pairs + n) + e * dout, "dw": fwd}
 
 
-def synthetic_on_device(n, e, r, din, dout, dev, seed=0):
+def synthetic_on_device(n, e, r, din, dout, dev, seed=0, skew=False):
+    """SURVEY.md 8d inputs, generated on the device.  skew: dst ~ Zipf(1.2)-tailed, mod N (the same law as
+    oracle.synthetic_graph(skew=True): P(dst >= k) = (k + 1)^-0.2 before the fold) -- KG hubs: node 0 receives 13 % of the
+    edges, the first 224 nodes two thirds."""
     g = torch.Generator(device=dev).manual_seed(seed)
     src = torch.randint(0, n, (e,), generator=g, device=dev)
-    dst = torch.randint(0, n, (e,), generator=g, device=dev)
+    if skew:
+        u = torch.rand(e, generator=g, device=dev, dtype=torch.float64)
+        dst = (torch.floor(u.pow(-5.0)).clamp_(max=2.0 ** 62).to(torch.int64) - 1) % n
+        del u
+    else:
+        dst = torch.randint(0, n, (e,), generator=g, device=dev)
     typ = torch.randint(0, r, (e,), generator=g, device=dev)
     x = torch.randn(n, din, generator=g, device=dev)
     dout_grad = torch.randn(n, dout, generator=g, device=dev)
@@ -128,21 +141,35 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5, graph=False):
+def plan_stats(plan):
+    """how full the plan's slots are: the forward / dX kernels pay per chunk and per 16-row tile, whatever they hold"""
+    real = int((plan.slot_w != 0).sum())
+    rows16 = int(plan.chunk_cnt.sum())
+    return {"tile": plan.tile, "chunk": plan.chunk, "layout": plan.layout, "tiles": plan.n_tiles, "chunks": plan.n_chunks,
+            "chunks_per_tile": plan.n_chunks / max(1, plan.n_tiles),
+            "slot_fill": real / max(1, plan.n_chunks * plan.chunk),          # real slots / allocated slots
+            "row_tile_fill": real / max(1, rows16),                          # real slots / slots of the used 16-row tiles
+            "rows_per_chunk": real / max(1, plan.n_chunks)}
+
+
+def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5, graph=False, num_bases=None, skew=False):
     """fwd + bwd of one layer through the drop-in module on a fresh synthetic graph: (median ms per step, plan s)"""
     from scaling_rgcn_training_amd.conv import RGCNConv
     from scaling_rgcn_training_amd.plan import clear_plan_cache
-    ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, din, dout, dev, seed=1)
-    conv = RGCNConv(din, dout, r).to(dev)
+    ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, din, dout, dev, seed=1, skew=skew)
+    conv = RGCNConv(din, dout, r, num_bases=num_bases).to(dev)
     with torch.no_grad():
-        conv.weight.copy_(weight)
+        if num_bases is None:
+            conv.weight.copy_(weight)
         conv.root.copy_(root)
     x.requires_grad_(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    conv._plans(x, ei, et)
+    plans = conv._plans(x, ei, et)
     torch.cuda.synchronize()
     plan_s = time.perf_counter() - t0
+    stats = plan_stats(plans.fwd)
+    del plans
     evs = []
     for i in range(warmup + steps):
         x.grad = None
@@ -176,7 +203,7 @@ def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5, graph=False):
         ms_graph = statistics.median(a.elapsed_time(b) for a, b in evs)
         del g
     clear_plan_cache()
-    return ms, plan_s, ms_graph
+    return ms, plan_s, ms_graph, stats
 
 
 def main():
@@ -481,10 +508,12 @@ def main():
         if not args.no_ladder:
             ladder = [{"rung": "10M/100M", "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
                        "gpu_ms_per_step": rec["ms_per_step_median"], "gpu_edges_per_s": e / (rec["ms_per_step_median"] * 1e-3)}]
-            for name, ln, le, lr, lin, lout in LADDER:
-                ms, ps_, msg = gpu_rung(ln, le, lr, lin, lout, dev, graph=le <= 1_000_000)
+            for name, ln, le, lr, lin, lout, nb in LADDER:
+                ms, ps_, msg, st = gpu_rung(ln, le, lr, lin, lout, dev, graph=le <= 1_000_000, num_bases=nb)
                 ladder.append({"rung": name, "nodes": ln, "edges": le, "relations": lr, "in": lin, "out": lout,
-                               "gpu_ms_per_step": ms, "gpu_edges_per_s": le / (ms * 1e-3), "plan_build_s": ps_})
+                               "gpu_ms_per_step": ms, "gpu_edges_per_s": le / (ms * 1e-3), "plan_build_s": ps_, "plan": st})
+                if nb is not None:
+                    ladder[-1]["num_bases"] = nb
                 if msg is not None:
                     ladder[-1]["gpu_ms_per_step_hipgraph_replay"] = msg
                 log(f"ladder {name}: {ms:.3f} ms/step = {le / (ms * 1e-3):.3e} edges/s" +

@@ -42,9 +42,9 @@ _ENV_CHUNK = int(os.environ["RGCN_CHUNK"]) if "RGCN_CHUNK" in os.environ else No
 # forward / dX on the bf16 x 3 kernel whose PRODUCER waves split the gathered rows (csrc/rgcn_tile3p.hip):
 # fp32-equivalent arithmetic; layers padded to 64 x 64 on graphs dense enough for 128-slot chunks.  "1" / "0" / "auto"
 _SPLIT_PRODUCERS_DEFAULT = os.environ.get("RGCN_SPLIT_PRODUCERS", "1")
-# plans of those layers in the TEAM placement (plan layout 1, plan.team_placement): two teams of consumer waves per workgroup
-# accumulate the two destination-disjoint parts of every chunk side by side.  "0": layout 0 and the one-team kernel (round 2)
-_TEAM_LAYOUT_DEFAULT = os.environ.get("RGCN_TEAM_LAYOUT", "1") == "1"
+# "1": plans of those layers in the TEAM placement (plan layout 1, plan.team_placement) for experiment builds of the kernel
+# with two teams of consumer waves (csrc/rgcn_tile3p.hip RGCN_P3_TEAMS=2: measured no faster).  Default: layout 0
+_TEAM_LAYOUT_DEFAULT = os.environ.get("RGCN_TEAM_LAYOUT", "0") == "1"
 SPLIT_PRODUCERS_TILE = 224       # the largest tile whose fp32 accumulator fits beside the kernel's two 48 KiB ring slots
 DW_TILES_MIN_EDGES = 4_000_000
 
@@ -324,7 +324,7 @@ class RGCNConv(nn.Module):
         # equivalent arithmetic (24-bit operand significands, exact products, fp32 accumulation), 1 ms per step faster at
         # the headline config.  False (or RGCN_SPLIT_PRODUCERS=0): the exact-fp32 MFMA kernel everywhere
         self.split_producers = _SPLIT_PRODUCERS_DEFAULT == "1"
-        self.team_layout = _TEAM_LAYOUT_DEFAULT     # plans of such layers in the team placement (two consumer teams per workgroup)
+        self.team_layout = _TEAM_LAYOUT_DEFAULT     # plans of such layers in the team placement (experiment builds: two consumer teams)
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
             self.comp = nn.Parameter(torch.empty(num_relations, num_bases))

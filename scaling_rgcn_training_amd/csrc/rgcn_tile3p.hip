@@ -581,9 +581,9 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
             P3A(sc_meta, t0s, t1s); P3A(sc_comp, t1s, t2s); P3A(sc_swap, t2s, t3s); P3A(sc_bar, t3s, t4s);
         }
 #ifdef RGCN_P3_STAMPS
-        if (g_p3_stamps && cw == 0 && lane == 0) {
-            unsigned long long* o = g_p3_stamps + (size_t)blockIdx.x * 16;
-            o[8] = sc_meta; o[9] = sc_comp; o[10] = sc_swap; o[11] = sc_bar;
+        if (g_p3_stamps && (cw == 0 || cw == kConsumers - 1) && lane == 0) {       // first wave of team A, last wave of team B
+            unsigned long long* o = g_p3_stamps + (size_t)blockIdx.x * 16 + (cw == 0 ? 8 : 12);
+            o[0] = sc_meta; o[1] = sc_comp; o[2] = sc_swap; o[3] = sc_bar;
         }
 #endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the consumers is pending when the producer code follows
@@ -600,11 +600,18 @@ static size_t p3_lds_bytes(int tile) {
 // Launch (called by run_tile in rgcn_tile_fp32.hip when RGCN_FLAG_SPLIT_PRODUCERS is set and the shapes fit): `a.wp` points at
 // the bf16 planes of the packed weights.  Layout-1 plans run the two-team form, layout-0 plans the one-team form.
 // Returns RGCN_ERR_LDS / RGCN_ERR_PLAN when it does not apply.
+// The two-team forms are EXPERIMENT builds (tools/debug/build_variant_p3.sh -DRGCN_P3_TEAMS=2 [-DRGCN_P3_NCT=2]): parity-green
+// (tests/test_gpu_parity.py::test_split_producers_kernel_matches_oracle runs whatever form the library was built with on
+// layout-1 plans), not faster -- round 3, forward launch at the headline config on a graph without repeated (dst, relation)
+// pairs, A/B on one box: one team 9.09 ms, two teams x four 16-column owners (8 consumer waves) 9.16, two teams x two
+// 32-column owners (half the operand reads) 9.47; stamps: a consumer's time per row tile grows from 468 to 650-820 cycles
+// when eight waves share the LDS (profiles/r03a_*).  The product library instantiates the one-team kernel only; any
+// placement is valid for it.
 #ifndef RGCN_P3_NCT          // 16-column tiles per consumer wave of the two-team form (1: 8 consumer waves, 2: 4)
 #define RGCN_P3_NCT 1
 #endif
-#ifndef RGCN_P3_TEAMS        // experiment knob: 1 runs layout-1 plans on the one-team kernel (any placement is valid for it)
-#define RGCN_P3_TEAMS 2
+#ifndef RGCN_P3_TEAMS        // 2: layout-1 plans run the two-team kernel
+#define RGCN_P3_TEAMS 1
 #endif
 template <int TEAMS, int NCT>
 static int launch_tile3p_as(const TileArgs& b, int nwg, size_t lds, hipStream_t stream) {
@@ -631,7 +638,8 @@ int launch_tile3p(const TileArgs& a, int n_tiles, int layout, void* stream) {
     TileArgs b = a;
     if (n_tiles < 16 * 256) b.tiles_per_wg = 1;
     const int nwg = (n_tiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
-    if (layout == 1 && RGCN_P3_TEAMS == 2) return launch_tile3p_as<2, RGCN_P3_NCT>(b, nwg, lds, (hipStream_t)stream);
+    if constexpr (RGCN_P3_TEAMS == 2)
+        if (layout == 1) return launch_tile3p_as<2, RGCN_P3_NCT>(b, nwg, lds, (hipStream_t)stream);
     return launch_tile3p_as<1, 1>(b, nwg, lds, (hipStream_t)stream);
 }
 

@@ -506,7 +506,6 @@ def test_split_producers_through_the_module(dev):
         out = conv(xd, eid, etd, _input_relu=True)
         out.backward(dg.to(dev))
         assert conv._plans(xd, eid, etd).fwd.tile <= (224 if on else 352)
-        assert conv._plans(xd, eid, etd).fwd.layout == int(on)       # the two-team form of the kernel runs on team-placement plans
         with torch.no_grad():
             act = conv(xd, eid, etd, _activation="relu")
         outs.append([t.detach().cpu().numpy() for t in (out, xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad, act)])

@@ -8,8 +8,9 @@ B = os.path.join(ROOT, "scaling_rgcn_training_amd", "_build")
 so = os.path.join(ROOT, "gpurun_out", "librgcn_p3stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 H = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-subprocess.run(H + ["-DRGCN_P3_STAMPS", "-c", os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_tile3p.hip"), "-o", so + ".o"], check=True)
-subprocess.run(H + ["-shared", os.path.join(B, "rgcn_kernels.o"), os.path.join(B, "rgcn_dw_root.o"), os.path.join(B, "rgcn_plan.o"), so + ".o", "-o", so], check=True)
+DEFS = os.environ.get("P3_DEFS", "").split()
+subprocess.run(H + ["-DRGCN_P3_STAMPS"] + DEFS + ["-c", os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_tile3p.hip"), "-o", so + ".o"], check=True)
+subprocess.run(H + ["-shared"] + [os.path.join(B, f"rgcn_{n}.o") for n in ("tile_fp32", "dw_relmajor", "dw_tile", "dw_root", "abi", "plan")] + [so + ".o", "-o", so], check=True)
 from scaling_rgcn_training_amd import _lib
 _lib.LIB_PATH = so
 lib = _lib.load()
@@ -18,7 +19,10 @@ import bench
 n, e = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10_000_000, 100_000_000)
 dev = torch.device("cuda:0")
 ei, et, x, dg, w, root = bench.synthetic_on_device(n, e, 32, 64, 64, dev)
-plans = P.build_graph_plans_device(ei, et, n, 32, 224, chunk=128, dw_tiles=False)
+if os.environ.get("VT_UNIQ") == "1":
+    key = torch.randperm(n * 32, device=dev)[:e]
+    ei = torch.stack([ei[0], key // 32]); et = key % 32
+plans = P.build_graph_plans_device(ei, et, n, 32, 224, chunk=128, dw_tiles=False, split=os.environ.get("VT_SPLIT", "0") == "1")
 fp = plans.fwd
 stamps = torch.zeros(fp.n_tiles * 16, dtype=torch.int64, device=dev)
 lib.rgcn_debug_set_p3_stamps.argtypes = [ctypes.c_void_p]
@@ -31,8 +35,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64)
 nch = s[:, 4].sum()
-print("tiles", fp.n_tiles, "chunks", int(nch))
+print("defs", DEFS, "layout", fp.layout, "tiles", fp.n_tiles, "chunks", int(nch))
 for i, nm in ((0, "prod wait batch"), (1, "prod issue batch"), (2, "prod split + store"), (3, "prod barrier"),
-              (8, "cons metadata"), (9, "cons compute"), (10, "cons W swap + prefetch"), (11, "cons barrier")):
+              (8, "cons metadata"), (9, "cons compute"), (10, "cons W swap + prefetch"), (11, "cons barrier"),
+              (12, "consB metadata"), (13, "consB compute"), (14, "consB W swap + prefetch"), (15, "consB barrier")):
     print(f"{nm:24s} {s[:, i].sum() / nch:9.1f} cycles/chunk")
 print("producer total %.1f  consumer total %.1f" % (s[:, 0:4].sum() / nch, s[:, 8:12].sum() / nch))
