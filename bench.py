@@ -168,7 +168,13 @@ def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5, graph=False, num_bases
     plans = conv._plans(x, ei, et)
     torch.cuda.synchronize()
     plan_s = time.perf_counter() - t0
-    stats = plan_stats(plans.fwd)
+    if plans.fwd is not None:
+        stats = plan_stats(plans.fwd)
+    else:       # edge-parallel forward: dense relation-major units
+        ep = plans.ep_fwd
+        stats = {"units": ep.n_units, "slot_fill": ep.n_rows / max(1, ep.n_units * 64), "max_rows_per_dst": ep.max_rows_per_dst,
+                 "sum_levels": len(ep.levels)}
+    stats["path"] = {"fwd": "ep" if plans.ep_fwd is not None else "ring", "dx": "ep" if plans.ep_bwd is not None else "ring"}
     del plans
     evs = []
     for i in range(warmup + steps):

@@ -85,8 +85,9 @@ typedef struct rgcn_plan {
     int32_t layout;        /* 0: the rows of a (tile, relation) group are dealt over all its row tiles; 1 (chunk = 128): TEAM
                             * placement -- a chunk's rows are cut at a change of destination into part A on its first
                             * ceil(nt / 2) row tiles and part B on the others, so the two parts scatter into disjoint rows
-                            * (chunk_flags bit 8: they do not) and the forward / dX kernel of 64 x 64 layers gives each
-                            * part to its own team of consumer waves; same chunks and row-tile counts as layout 0 */
+                            * (chunk_flags bit 8: they do not) and experiment builds of the forward / dX kernel of 64 x 64 layers give
+                            * each part to its own team of consumer waves; same chunks and row-tile counts as layout 0;
+                            * 2: no tiles -- dense relation-major units for rgcn_bwd_dw only (rgcn_edge_units) */
     int32_t reserved;
     const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
     const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */
@@ -227,6 +228,36 @@ int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_ptr, const fl
 size_t rgcn_bwd_dw_root_workspace_bytes(void);
 int rgcn_bwd_dw_root(const float* x, int ldx, int din, const float* g, int ldg, int dout, long rows, void* workspace,
                      size_t workspace_bytes, float* d_root, float* d_bias, void* stream);
+
+/* ---- edge-parallel path (scaling_rgcn_training_amd/eplan.py) ---------------------------------------------------
+ * The same layer arithmetic for graphs on which the tile-major plan is the wrong shape -- the reference's own datasets
+ * (model/modelTrainer.py:78,92: 45 .. ~267 relation ids, hubs of in-degree 10^4 on 8k nodes): rows (merged edges + one
+ * root pseudo edge per node) sorted RELATION-MAJOR and packed into dense 64-slot units; rgcn_ep_transform writes
+ * Z[slot] = w_slot * (x[src_slot] @ W_rel) for every slot, rgcn_ep_segment_sum adds the rows of every destination in a
+ * fixed order and applies bias / activation / ReLU mask.  dX: the same two calls on the transposed units with W^T.
+ * The units double as a dense relation-major walk for rgcn_bwd_dw (a rgcn_plan_t with layout = 2, chunk = 64, rel_order
+ * = 0 .. n_units - 1, chunk_rel / chunk_cnt = unit_rel / unit_cnt: rgcn_fwd / rgcn_bwd_dx refuse it). */
+typedef struct rgcn_edge_units {
+    int32_t n_nodes;           /* rows of the gathered matrix (padding slots gather row n_nodes -> zeros) */
+    int32_t n_units;           /* 64-slot units */
+    int32_t num_relations;     /* R' (the root pseudo relation is id R') */
+    int32_t reserved;
+    const int32_t* unit_rel;   /* [n_units] relation of the unit, ascending */
+    const int32_t* unit_cnt;   /* [n_units] used slots rounded up to 16 (whole MFMA row tiles): 16 .. 64 */
+    const int32_t* slot_src;   /* [n_units * 64] */
+    const float* slot_w;       /* [n_units * 64] edge weight, 0 = padding */
+} rgcn_edge_units_t;
+
+/* z: [n_units * 64, ldz] (rows of unused row tiles are left untouched); packed_w: rgcn_pack_weights(..., transpose) */
+int rgcn_ep_transform(const rgcn_edge_units_t* units, const float* x, int ldx, int din, const float* packed_w, float* z,
+                      int ldz, int dout, unsigned flags, void* stream);
+/* out[i] = sum of rows seg_idx[q] (q itself when seg_idx is NULL) of `in` for q in [seg_ptr[i], seg_ptr[i + 1]), i < n_out,
+ * added in index order; final_level != 0: + bias (may be NULL), activation (RGCN_ACT_*), then out *= (mask > 0) when mask
+ * is given (rows of the layer input when it is a ReLU output, as rgcn_bwd_dx's relu_of).  Long segments are summed in
+ * levels: pieces first (final_level = 0, seg_idx of the first level only), the pieces of a segment last. */
+int rgcn_ep_segment_sum(const float* in, int ldin, const int32_t* seg_ptr, const int32_t* seg_idx, int n_out, int width,
+                        const float* bias, int act, const float* mask, int ldm, int final_level, float* out, int ldo,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ EXPORTS = (
     "rgcn_pack_weights", "rgcn_fwd", "rgcn_bwd_dx", "rgcn_act_backward", "rgcn_bwd_dw_workspace_bytes", "rgcn_bwd_dw",
     "rgcn_plan_workspace_bytes", "rgcn_edge_weights", "rgcn_plan_build_begin", "rgcn_plan_build_finish",
     "rgcn_dw_tiles_geometry", "rgcn_dw_tiles_walk", "rgcn_bwd_dw_tiles_workspace_bytes", "rgcn_bwd_dw_tiles",
-    "rgcn_bwd_dw_root_workspace_bytes", "rgcn_bwd_dw_root",
+    "rgcn_bwd_dw_root_workspace_bytes", "rgcn_bwd_dw_root", "rgcn_ep_transform", "rgcn_ep_segment_sum",
 )
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
@@ -40,6 +40,12 @@ class RgcnPlanStruct(C.Structure):
         ("chunk_tile", C.c_void_p), ("chunk_flags", C.c_void_p), ("rel_order", C.c_void_p), ("slot_src", C.c_void_p),
         ("slot_w", C.c_void_p), ("slot_row", C.c_void_p), ("slot_acc", C.c_void_p),
     ]
+
+
+class RgcnEdgeUnits(C.Structure):
+    """struct rgcn_edge_units of include/rgcn_mi355x.h"""
+    _fields_ = [("n_nodes", C.c_int32), ("n_units", C.c_int32), ("num_relations", C.c_int32), ("reserved", C.c_int32),
+                ("unit_rel", C.c_void_p), ("unit_cnt", C.c_void_p), ("slot_src", C.c_void_p), ("slot_w", C.c_void_p)]
 
 
 class RgcnGraphStruct(C.Structure):
@@ -116,6 +122,10 @@ def load() -> C.CDLL:
     lib.rgcn_bwd_dw_root_workspace_bytes.argtypes = []
     lib.rgcn_bwd_dw_root.restype = i32
     lib.rgcn_bwd_dw_root.argtypes = [vp, i32, i32, vp, i32, i32, C.c_long, vp, sz, vp, vp, vp]
+    lib.rgcn_ep_transform.restype = i32
+    lib.rgcn_ep_transform.argtypes = [C.POINTER(RgcnEdgeUnits), vp, i32, i32, vp, vp, i32, i32, u32, vp]
+    lib.rgcn_ep_segment_sum.restype = i32
+    lib.rgcn_ep_segment_sum.argtypes = [vp, i32, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp]
     if lib.rgcn_abi_version() != ABI_VERSION:
         raise RgcnLibraryError(f"ABI version mismatch: library {lib.rgcn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
@@ -312,3 +322,36 @@ def bwd_dw_root(x: torch.Tensor, din: int, g: torch.Tensor, dout: int, d_root: O
         ws = torch.empty(lib.rgcn_bwd_dw_root_workspace_bytes(), dtype=torch.uint8, device=x.device)
         check(lib.rgcn_bwd_dw_root(x.data_ptr(), x.stride(0), din, g.data_ptr(), g.stride(0), dout, x.shape[0],
                                    ws.data_ptr(), ws.numel(), _ptr(d_root), _ptr(d_bias), _stream(x)), "rgcn_bwd_dw_root")
+
+
+# ---- edge-parallel path (eplan.EdgePlan) ----------------------------------------------------------------------------
+def edge_units_struct(ep) -> RgcnEdgeUnits:
+    cached = getattr(ep, "_cunits", None)
+    if cached is None:
+        if ep.slot_src.device.type != "cuda":
+            raise RgcnLibraryError("the edge plan must live on the GPU (plan tensors are on %s)" % ep.slot_src.device)
+        cached = ep._cunits = RgcnEdgeUnits(ep.n_nodes, ep.n_units, ep.num_relations, 0, ep.unit_rel.data_ptr(),
+                                            ep.unit_cnt.data_ptr(), ep.slot_src.data_ptr(), ep.slot_w.data_ptr())
+    return cached
+
+
+def ep_layer(ep, x: torch.Tensor, din: int, packed: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, dout: int,
+             act: int = ACT_NONE, mask: Optional[torch.Tensor] = None, flags: int = 0) -> None:
+    """out[:n_owned] = act(bias + sum over the plan's rows of w * (x[src] @ W_rel)) * (mask > 0): rgcn_ep_transform, then one
+    rgcn_ep_segment_sum per level of the plan.  ``out``: [n_owned, ld] with ld a multiple of 4."""
+    lib = load()
+    ldz = out.stride(0)
+    st = _stream(x)
+    with torch.cuda.device(x.device):
+        z = torch.empty(max(ep.n_units, 1) * 64, ldz, dtype=torch.float32, device=x.device)
+        check(lib.rgcn_ep_transform(C.byref(edge_units_struct(ep)), x.data_ptr(), x.stride(0), din, packed.data_ptr(),
+                                    z.data_ptr(), ldz, dout, int(flags), st), "rgcn_ep_transform")
+        cur = z
+        for li, (ptr, idx, n_out) in enumerate(ep.levels):
+            final = li == len(ep.levels) - 1
+            dst = out if final else torch.empty(max(n_out, 1), ldz, dtype=torch.float32, device=x.device)
+            check(lib.rgcn_ep_segment_sum(cur.data_ptr(), ldz, ptr.data_ptr(), _ptr(idx), n_out, dout,
+                                          _ptr(bias) if final else None, act if final else ACT_NONE,
+                                          _ptr(mask) if final else None, mask.stride(0) if (final and mask is not None) else 0,
+                                          int(final), dst.data_ptr(), dst.stride(0), st), "rgcn_ep_segment_sum")
+            cur = dst

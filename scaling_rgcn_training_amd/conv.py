@@ -45,6 +45,7 @@ _SPLIT_PRODUCERS_DEFAULT = os.environ.get("RGCN_SPLIT_PRODUCERS", "1")
 # "1": plans of those layers in the TEAM placement (plan layout 1, plan.team_placement) for experiment builds of the kernel
 # with two teams of consumer waves (csrc/rgcn_tile3p.hip RGCN_P3_TEAMS=2: measured no faster).  Default: layout 0
 _TEAM_LAYOUT_DEFAULT = os.environ.get("RGCN_TEAM_LAYOUT", "0") == "1"
+_PATH_DEFAULT = os.environ.get("RGCN_PATH", "auto")       # auto | ring | ep
 SPLIT_PRODUCERS_TILE = 224       # the largest tile whose fp32 accumulator fits beside the kernel's two 48 KiB ring slots
 DW_TILES_MIN_EDGES = 4_000_000
 
@@ -162,7 +163,11 @@ class _RGCNLayerFn(torch.autograd.Function):
         bs = None if bias is None else bias.detach().float().contiguous()
         packed = _lib.pack_weights(wf, rt, transpose=False)
         ldo = _round4(dout)
-        if dctx is None:
+        if dctx is None and plans.ep_fwd is not None:
+            # edge-parallel path (eplan.py): relation-major dense units -> weighted products per slot -> per-destination sums
+            out = torch.empty(n, ldo, dtype=torch.float32, device=x.device)
+            _lib.ep_layer(plans.ep_fwd, xp, din, packed, bs, out, dout, act, None, flags)
+        elif dctx is None:
             out = torch.empty(n, ldo, dtype=torch.float32, device=x.device)
             _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, out, dout, act, flags)
         else:
@@ -210,7 +215,7 @@ class _RGCNLayerFn(torch.autograd.Function):
         # with a tenth of a launch's MFMAs, uses no LDS and few registers, so its workgroups share the CUs with the MFMA-bound
         # dX kernel instead of adding their ~1 ms behind it.  The join is a stream wait, never a host sync.
         dwp = getattr(plans, "dw", None) if dctx is None else None
-        tiles_path = (dwp is not None and need_w and plans.fwd.n_owned > 0 and
+        tiles_path = (dwp is not None and need_w and plans.fwd is not None and plans.fwd.n_owned > 0 and
                       not (flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)) and
                       _lib.buffer_addressable(n, xp.shape[1]) and _lib.buffer_addressable(n, gp.shape[1]))
         tiles_part = side = None
@@ -229,7 +234,10 @@ class _RGCNLayerFn(torch.autograd.Function):
             packed_t = _lib.pack_weights(wf, rt, transpose=True)
             ldx = _round4(din)
             mask = xp if ctx.input_relu else None            # x = relu(z_prev): store dL/dz_prev = dx * (x > 0)
-            if dctx is None:
+            if dctx is None and plans.ep_bwd is not None:
+                dxp = torch.empty(n, ldx, dtype=torch.float32, device=dev)
+                _lib.ep_layer(plans.ep_bwd, gp, dout, packed_t, None, dxp, din, _lib.ACT_NONE, mask, flags)
+            elif dctx is None:
                 dxp = torch.empty(n, ldx, dtype=torch.float32, device=dev)
                 _lib.bwd_dx(_lib.plan_struct(plans.bwd), gp, dout, packed_t, dxp, din, mask, flags)
             else:
@@ -246,7 +254,8 @@ class _RGCNLayerFn(torch.autograd.Function):
                 torch.cuda.current_stream(dev).wait_stream(side)
             dw, droot, dbias = views(tiles_part)
         elif need_w or need_root or need_bias:
-            fplans = [plans.fwd] if dctx is None else [p.fwd for p in plans.pieces]
+            # (an edge-parallel forward hands its dense relation-major units to the same kernels: GraphPlans.fwd_walk)
+            fplans = [plans.fwd_walk] if dctx is None else [p.fwd for p in plans.pieces]
             acc = None
             for fp in fplans:
                 if fp.n_owned <= 0:
@@ -324,6 +333,10 @@ class RGCNConv(nn.Module):
         # equivalent arithmetic (24-bit operand significands, exact products, fp32 accumulation), 1 ms per step faster at
         # the headline config.  False (or RGCN_SPLIT_PRODUCERS=0): the exact-fp32 MFMA kernel everywhere
         self.split_producers = _SPLIT_PRODUCERS_DEFAULT == "1"
+        # "auto": per direction, the tile kernels or the edge-parallel path (csrc/rgcn_ep.hip), whichever eplan.choose_path
+        # expects to be faster on the graph (many relations / few tiles / hubs -> edge-parallel); "ring" / "ep" or a
+        # (forward, dX) pair pins it.  RGCN_PATH in the environment at import time sets the default.
+        self.path = _PATH_DEFAULT
         self.team_layout = _TEAM_LAYOUT_DEFAULT     # plans of such layers in the team placement (experiment builds: two consumer teams)
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
@@ -387,8 +400,11 @@ class RGCNConv(nn.Module):
                         and self.num_relations <= 32 and e >= DW_TILES_MIN_EDGES and x.is_cuda
                         and _lib.buffer_addressable(n, _round4(self.in_channels))
                         and _lib.buffer_addressable(n, _round4(self.out_channels)))
+            paths = self.path if self.path in ("auto",) else ((self.path, self.path) if isinstance(self.path, str) else tuple(self.path))
+            if not x.is_cuda:
+                paths = ("ring", "ring")
             return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split,
-                                      dw_tiles=dw_tiles)
+                                      dw_tiles=dw_tiles, paths=paths, widths=(self.in_channels, self.out_channels))
         from .dist import cached_rank_plans
         return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split)
 
@@ -421,7 +437,7 @@ class RGCNConv(nn.Module):
             raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
         plans = self._plans(x, edge_index, edge_type)
         flags = self.kernel_flags
-        first = plans.fwd if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
+        first = (plans.fwd if plans.fwd is not None else plans.bwd) if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
         if first is not None and self._use_split_producers(first.chunk):
             flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles; the library falls back where it does not fit
         return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist,

@@ -677,6 +677,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
                     float* out, int ldo, int nout, int act, const float* mask, int ldm, unsigned flags, void* stream) {
     int st = check_plan(plan);
     if (st != RGCN_OK) return st;
+    if (plan->layout == 2) return RGCN_ERR_PLAN;        // relation-major units: nothing tile-major to walk (rgcn_ep_*)
     if (!x || !packed || !out) return RGCN_ERR_NULL;
     if ((st = check_stride(ldx, kin)) != RGCN_OK) return st;
     if ((st = check_stride(ldo, nout)) != RGCN_OK) return st;

@@ -1,0 +1,229 @@
+"""Edge plan: the HBM layout of the EDGE-PARALLEL path of the layer (csrc/rgcn_ep.hip).
+
+The tile-major plan (plan.py) gives one workgroup a tile of output nodes and walks the (tile, relation) groups of its
+edges chunk by chunk: right where a group fills its chunks (the 10M-node / 100M-edge / 32-relation headline: 70 rows
+per group) and there are hundreds of tiles per CU.  It is the wrong shape for the graphs the reference actually trains
+on (/root/reference/model/modelTrainer.py:78,92: R' = 2R + 1 = 89 / 45 / ~267 relations; graphs/AIFB/attr/sum/
+AIFB_sum_in.nt: 49,838 edges onto 44 nodes, one of them with in-degree 11,825): few tiles (AIFB: 17 of 256 CUs busy),
+a chunk per (tile, relation) whatever it holds, and a hub's tile walked by ONE workgroup.
+
+Here the same arithmetic -- ``out[i] = bias + sum_e w_e (x[src_e] @ W_rel_e)`` over the edges e into i, the self loop
+being relation R' with one pseudo edge per node (torch_geometric RGCNConv, called at model/layers.py:21,23) -- is cut
+the other way:
+
+* rows (merged duplicate triples, as in plan.py) sorted RELATION-MAJOR and packed into dense 64-slot UNITS (only the last
+  unit of a relation is padded): ``rgcn_ep_transform`` multiplies every 16-row tile by its relation's weights on the
+  matrix cores and writes the weighted products Z, one row per slot -- any number of waves side by side, no ownership;
+* a destination-major index over those slots (``seg_ptr`` / ``seg_idx``): ``rgcn_ep_segment_sum`` adds the rows of every
+  destination in a fixed order (bit-reproducible, no atomics) and applies bias / activation / ReLU mask.  Destinations
+  with more than ``PIECE`` rows are summed in levels (pieces of at most PIECE rows, then the pieces of a destination,
+  ...), so that a hub costs as many waves as it has pieces.
+
+The same units are a dense relation-major walk for the weight-gradient kernels (``as_tile_plan``: rgcn_bwd_dw reads
+nothing but slots and units), where the tile-major plan's units hold a handful of rows each on such graphs.
+
+Cost: Z is written and read once (2 x rows x 4 x out bytes beside the gathers), which is why the headline graph stays on
+the tile kernels (``choose_path``).  The arrays are built with torch sorts (one-time, per graph and direction); unlike
+the tile-major plan there is no device builder behind the C ABI for them yet.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+UNIT = 64          # slots per unit (== plan.UNIT: what the weight-gradient kernels walk)
+PIECE = 256        # rows one lane group sums in a row before the sum goes through another level
+
+
+@dataclass
+class EdgePlan:
+    n_nodes: int            # rows of the gathered matrix
+    node_begin: int
+    node_end: int
+    num_relations: int      # R' (the root pseudo relation is id R')
+    n_units: int
+    n_rows: int             # real slots (merged edges + root pseudo edges)
+    unit_rel: Tensor        # int32 [n_units]
+    unit_cnt: Tensor        # int32 [n_units]  used slots of the unit rounded up to 16 (whole MFMA row tiles)
+    slot_src: Tensor        # int32 [n_units * 64]  row to gather (padding: n_nodes -> zeros)
+    slot_w: Tensor          # float32 [n_units * 64] (padding: 0)
+    slot_row: Tensor        # int32 [n_units * 64]  destination row inside the owned range (padding: n_owned)
+    levels: List[Tuple[Tensor, Optional[Tensor], int]]   # per level (seg_ptr int32 [n_out + 1], seg_idx int32 or None, n_out)
+    max_rows_per_dst: int
+    _tile_plan: object = field(default=None, repr=False)
+
+    @property
+    def n_owned(self) -> int:
+        return self.node_end - self.node_begin
+
+    @property
+    def device(self):
+        return self.slot_src.device
+
+    def nbytes(self) -> int:
+        ts = [self.unit_rel, self.unit_cnt, self.slot_src, self.slot_w, self.slot_row]
+        for p, i, _ in self.levels:
+            ts.append(p)
+            if i is not None:
+                ts.append(i)
+        return sum(t.numel() * t.element_size() for t in ts)
+
+    def as_tile_plan(self):
+        """The units as a plan.TilePlan the relation-major weight-gradient kernels accept (plan layout 2: they read
+        rel_order, chunk_rel, chunk_cnt and the slot arrays only; there are no tiles to walk -- rgcn_fwd / rgcn_bwd_dx
+        refuse such a plan)."""
+        if self._tile_plan is None:
+            from .plan import TilePlan
+            dev = self.device
+            n_own = self.n_owned
+            tile = min(32768, (n_own + 15) // 16 * 16)
+            n_tiles = (n_own + tile - 1) // tile
+            z = torch.zeros(self.n_units, dtype=torch.int32, device=dev)
+            self._tile_plan = TilePlan(
+                n_nodes=self.n_nodes, node_begin=self.node_begin, node_end=self.node_end, num_relations=self.num_relations,
+                tile=tile, chunk=UNIT, n_tiles=n_tiles, n_chunks=self.n_units, n_edges=self.n_rows - n_own,
+                tile_ptr=torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev), chunk_rel=self.unit_rel,
+                chunk_cnt=self.unit_cnt, chunk_tile=z, chunk_flags=z,
+                rel_order=torch.arange(self.n_units, dtype=torch.int32, device=dev), slot_src=self.slot_src,
+                slot_w=self.slot_w, slot_dstl=None, slot_row=self.slot_row, slot_acc=self.slot_row, layout=2)
+        return self._tile_plan
+
+
+def segment_levels(counts: Tensor, piece: int = PIECE):
+    """Reduction levels over segments of ``counts[i]`` consecutive input rows.  One level if no segment is longer than
+    ``piece``; else level 0 sums pieces of at most ``piece`` consecutive rows and the next levels sum the pieces of a
+    segment the same way.  Returns [(seg_ptr int64 [n_out + 1], n_out)], level 0 over the input rows."""
+    levels = []
+    cnt = counts.to(torch.int64)
+    while True:
+        if int(cnt.max()) <= piece if cnt.numel() else True:
+            ptr = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=cnt.device)
+            ptr[1:] = torch.cumsum(cnt, 0)
+            levels.append((ptr, int(cnt.numel())))
+            return levels
+        npieces = (cnt + piece - 1) // piece                       # pieces of every segment (0 for an empty one)
+        seg_of_piece = torch.repeat_interleave(torch.arange(cnt.numel(), device=cnt.device), npieces)
+        first_piece = torch.cumsum(npieces, 0) - npieces
+        k = torch.arange(seg_of_piece.numel(), device=cnt.device) - first_piece[seg_of_piece]
+        start = (torch.cumsum(cnt, 0) - cnt)[seg_of_piece] + k * piece
+        size = torch.minimum(cnt[seg_of_piece] - k * piece, torch.full_like(k, piece))
+        ptr = torch.cat([start, (start[-1:] + size[-1:])])
+        levels.append((ptr, int(seg_of_piece.numel())))
+        cnt = npieces
+
+
+def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes: int, num_relations: int,
+                    node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE) -> EdgePlan:
+    """gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src); w: the edge weights of
+    plan.edge_weights (1 / max(1, c[dst, rel]) for aggr = 'mean'), kept for both directions."""
+    if node_end is None:
+        node_end = n_nodes
+    dev = gather.device
+    n_own = node_end - node_begin
+    r1 = num_relations + 1
+    gather, scatter, rel = gather.to(torch.int64), scatter.to(torch.int64), rel.to(torch.int64)
+    if rel.numel() and (int(rel.min()) < 0 or int(rel.max()) >= num_relations):
+        raise ValueError("edge_type out of range [0, num_relations)")
+    if gather.numel() and (int(gather.min()) < 0 or int(gather.max()) >= n_nodes
+                           or int(scatter.min()) < 0 or int(scatter.max()) >= n_nodes):
+        raise ValueError("edge_index out of range [0, num_nodes)")
+    own = (scatter >= node_begin) & (scatter < node_end)
+    if not bool(own.all()):
+        gather, scatter, rel, w = gather[own], scatter[own], rel[own], w[own]
+    nodes = torch.arange(node_begin, node_end, device=dev, dtype=torch.int64)
+    g_all = torch.cat([gather, nodes])
+    loc = torch.cat([scatter, nodes]) - node_begin
+    r_all = torch.cat([rel, torch.full((n_own,), num_relations, device=dev, dtype=torch.int64)])
+    w_all = torch.cat([w.to(torch.float32), torch.ones(n_own, device=dev, dtype=torch.float32)])
+    # relation-major, then destination, then gathered row; duplicate (gather, scatter, relation) triples share one slot
+    # whose weight is the sum of theirs (plan.build_plan explains why: thousands of identical terms on the summary graphs)
+    key, perm = torch.sort((r_all * max(n_own, 1) + loc) * n_nodes + g_all)
+    w_all = w_all[perm]
+    key, inv = torch.unique_consecutive(key, return_inverse=True)
+    if key.shape[0] != w_all.shape[0]:
+        w_all = torch.zeros(key.shape[0], dtype=torch.float64, device=dev).index_add_(0, inv, w_all.to(torch.float64)).to(torch.float32)
+    n_rows = int(key.shape[0])
+    g_all = key % n_nodes
+    rd = key // n_nodes
+    loc = rd % max(n_own, 1)
+    r_all = rd // max(n_own, 1)
+    rcnt = torch.bincount(r_all, minlength=r1)
+    runits = (rcnt + UNIT - 1) // UNIT
+    ubase = torch.cumsum(runits, 0) - runits
+    rstart = torch.cumsum(rcnt, 0) - rcnt
+    n_units = int(runits.sum())
+    slot = ubase[r_all] * UNIT + (torch.arange(n_rows, device=dev) - rstart[r_all])
+    n_slots = n_units * UNIT
+    slot_src = torch.full((n_slots,), n_nodes, dtype=torch.int32, device=dev)
+    slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+    slot_row = torch.full((n_slots,), n_own, dtype=torch.int32, device=dev)
+    slot_src[slot] = g_all.to(torch.int32)
+    slot_w[slot] = w_all
+    slot_row[slot] = loc.to(torch.int32)
+    unit_rel = torch.repeat_interleave(torch.arange(r1, device=dev), runits).to(torch.int32)
+    uidx = torch.arange(n_units, device=dev) - ubase[unit_rel.long()]
+    used = torch.clamp(rcnt[unit_rel.long()] - uidx * UNIT, max=UNIT)
+    unit_cnt = ((used + 15) // 16 * 16).to(torch.int32)
+    # destination-major index over the slots: stable, so a destination's rows stay in (relation, gathered row) order
+    order = torch.sort(loc, stable=True)[1]
+    seg_idx = slot[order].to(torch.int32)
+    dcnt = torch.bincount(loc, minlength=n_own)
+    lv = segment_levels(dcnt, piece)
+    levels = [(p.to(torch.int32), seg_idx if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
+    return EdgePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, n_units=n_units,
+                    n_rows=n_rows, unit_rel=unit_rel, unit_cnt=unit_cnt, slot_src=slot_src, slot_w=slot_w, slot_row=slot_row,
+                    levels=levels, max_rows_per_dst=int(dcnt.max()) if n_own else 0)
+
+
+# ---- which path: cost model of one forward / dX launch ---------------------------------------------------------------
+def ring_launch_us(n_nodes: int, n_edges: int, num_relations: int, width: int, tile: int, chunk: int,
+                   max_tile_rows: int) -> float:
+    """Time of a tile-kernel launch in microseconds: a chunk costs ~0.6 us plus ~0.2 us per 16-row tile at 64 columns
+    (stamp builds), a workgroup walks its tiles' chunks one after the other, 256 workgroups at a
+    time -- and the tile with the most rows (a hub's) is walked by ONE workgroup."""
+    import math
+    r1 = max(1, num_relations)
+    group = n_edges / max(1.0, float(n_nodes) * r1) * tile          # expected rows of a (tile, relation) group
+    wscale = max(16, width) / 64.0
+
+    def group_us(rows):
+        return math.ceil(rows / chunk) * 0.6 + 0.2 * wscale * math.ceil(rows / 16.0)
+
+    # the relations present in a tile: all of them once a group expects a few rows, else the expected number of non-empty groups
+    present = r1 * (1.0 - math.exp(-group)) if group < 8 else r1
+    per_tile = present * group_us(max(group, 1.0)) + group_us(float(tile))
+    rounds = math.ceil(math.ceil(n_nodes / tile) / 256)
+    return max(rounds * per_tile, group_us(float(max_tile_rows)))
+
+
+def ep_launch_us(n_nodes: int, n_edges: int, in_width: int, out_width: int) -> float:
+    """Edge-parallel path: gathers + Z written and read once at ~4 TB/s, plus two launches."""
+    rows = n_edges + n_nodes
+    return rows * (4.0 * in_width + 8.0 * out_width + 24.0) / 4.0e6 + 12.0
+
+
+def choose_path(n_nodes: int, n_edges: int, num_relations: int, in_width: int, out_width: int, tile: int, chunk: int,
+                max_tile_rows: int) -> str:
+    """'ep' where the edge-parallel path is expected to be clearly faster than the tile kernel for this direction."""
+    ring = ring_launch_us(n_nodes, n_edges, num_relations, max(in_width, out_width), tile, chunk, max_tile_rows)
+    ep = ep_launch_us(n_nodes, n_edges, in_width, out_width)
+    return "ep" if ep < 0.7 * ring else "ring"
+
+
+def decide_paths(edge_index: Tensor, n_nodes: int, num_relations: int, in_channels: int, out_channels: int, tile: int,
+                 chunk: int) -> Tuple[str, str]:
+    """(forward path, dX path) for a layer on this graph.  One pass over the edge list per direction (rows per tile: a hub's
+    tile is walked by one workgroup of the tile kernel) and one host read of the two maxima -- at plan time only."""
+    e = int(edge_index.shape[1])
+    n_tiles = (n_nodes + tile - 1) // tile
+    if e:
+        mx = torch.stack([torch.bincount(edge_index[1] // tile, minlength=n_tiles).max(),
+                          torch.bincount(edge_index[0] // tile, minlength=n_tiles).max()]).tolist()
+    else:
+        mx = [0, 0]
+    fwd = choose_path(n_nodes, e, num_relations, in_channels, out_channels, tile, chunk, int(mx[0]) + tile)
+    bwd = choose_path(n_nodes, e, num_relations, out_channels, in_channels, tile, chunk, int(mx[1]) + tile)
+    return fwd, bwd

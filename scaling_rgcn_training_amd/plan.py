@@ -403,28 +403,44 @@ def run_metadata(slot_dstl: Tensor, tile: int):
 
 @dataclass
 class GraphPlans:
-    """Forward plan (edges grouped by destination) + transposed plan (grouped by source)."""
-    fwd: TilePlan
-    bwd: TilePlan
+    """Forward plan (edges grouped by destination) + transposed plan (grouped by source).  A direction that runs the
+    edge-parallel path (eplan.choose_path) has an eplan.EdgePlan instead of a tile-major plan."""
+    fwd: Optional[TilePlan]
+    bwd: Optional[TilePlan]
     num_edges: int
     dw: Optional[TilePlan] = None        # forward-direction plan in the geometry of the tile-major dW kernel (dw_walk_table)
     dw_walk: Optional[Tensor] = None     # int32 [R'][walkers + 1]
+    ep_fwd: Optional[object] = None      # eplan.EdgePlan: forward on rgcn_ep_*, weight gradients on its dense units
+    ep_bwd: Optional[object] = None      # eplan.EdgePlan of the transposed graph: dX on rgcn_ep_*
+
+    @property
+    def fwd_walk(self) -> TilePlan:
+        """the plan whose 64-slot units the relation-major weight-gradient kernels walk"""
+        return self.fwd if self.fwd is not None else self.ep_fwd.as_tile_plan()
 
 
 def build_graph_plans_torch(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
                             tile: int, aggr: str = "mean",
                             fwd_range: Optional[Tuple[int, int]] = None,
                             bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
-                            split: bool = False) -> GraphPlans:
+                            split: bool = False, paths: Tuple[str, str] = ("ring", "ring")) -> GraphPlans:
     """The plans as torch tensor ops (any device): the TEST ORACLE of the device-side builder and what the CPU-only
-    tests walk with tests/plan_emulator.py."""
+    tests walk with tests/plan_emulator.py.  paths: 'ring' (tile-major plan) or 'ep' (eplan.EdgePlan) per direction."""
+    from .eplan import build_edge_plan
     src, dst = edge_index[0], edge_index[1]
     w = edge_weights(src, dst, edge_type, num_relations, aggr)
     fb, fe = fwd_range if fwd_range is not None else (0, n_nodes)
     bb, be = bwd_range if bwd_range is not None else (0, n_nodes)
-    fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe, chunk, split)
-    bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be, chunk, split)
-    return GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(edge_type.shape[0]))
+    gp = GraphPlans(fwd=None, bwd=None, num_edges=int(edge_type.shape[0]))
+    if paths[0] == "ep":
+        gp.ep_fwd = build_edge_plan(src, dst, edge_type, w, n_nodes, num_relations, fb, fe)
+    else:
+        gp.fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe, chunk, split)
+    if paths[1] == "ep":
+        gp.ep_bwd = build_edge_plan(dst, src, edge_type, w, n_nodes, num_relations, bb, be)
+    else:
+        gp.bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be, chunk, split)
+    return gp
 
 
 def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, tile: int, chunk: int,
@@ -447,7 +463,8 @@ def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, t
 def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
                              aggr: str = "mean", fwd_range: Optional[Tuple[int, int]] = None,
                              bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
-                             ranges=None, split: bool = False, dw_tiles: bool = False):
+                             ranges=None, split: bool = False, dw_tiles: bool = False,
+                             paths: Tuple[str, str] = ("ring", "ring")):
     """The plans built by the HIP library itself (csrc/rgcn_plan.hip through rgcn_edge_weights / rgcn_plan_build_*):
     what every GPU forward uses.  ``ranges``: a list of (begin, end) owned ranges -> a list of GraphPlans that share one
     edge-weight pass and one workspace (dist.py: one pair of plans per owned block)."""
@@ -468,10 +485,20 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
         raise
     out = []
     for (fb, fe), (bb, be) in rs:
-        fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws, split)
-        bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
-        gp = GraphPlans(fwd=fwd, bwd=bwd, num_edges=fwd.n_edges if ranges is not None else e)
-        if dw_tiles and ranges is None and (fb, fe) == (0, n_nodes):
+        gp = GraphPlans(fwd=None, bwd=None, num_edges=e)
+        if paths[0] == "ep":       # edge-parallel direction: torch sorts on the device (eplan.py), the library's edge weights
+            from .eplan import build_edge_plan
+            gp.ep_fwd = build_edge_plan(edge_index[0], edge_index[1], edge_type, w, n_nodes, num_relations, fb, fe)
+        else:
+            gp.fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws, split)
+            if ranges is not None:
+                gp.num_edges = gp.fwd.n_edges
+        if paths[1] == "ep":
+            from .eplan import build_edge_plan
+            gp.ep_bwd = build_edge_plan(edge_index[1], edge_index[0], edge_type, w, n_nodes, num_relations, bb, be)
+        else:
+            gp.bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
+        if dw_tiles and paths[0] != "ep" and ranges is None and (fb, fe) == (0, n_nodes):
             t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
             if num_relations <= max_rel:
                 gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, 0, n_nodes, ws, False)
@@ -497,12 +524,13 @@ def build_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_r
                       tile: int, aggr: str = "mean",
                       fwd_range: Optional[Tuple[int, int]] = None,
                       bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
-                      split: bool = False, dw_tiles: bool = False) -> GraphPlans:
+                      split: bool = False, dw_tiles: bool = False, paths: Tuple[str, str] = ("ring", "ring")) -> GraphPlans:
     """Device tensors: the HIP plan builder behind the C ABI.  CPU tensors (tests without a GPU): the torch form."""
     if edge_type.device.type == "cuda" and _WALK_MODE == "sorted":
         return build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk,
-                                        split=split, dw_tiles=dw_tiles)
-    return build_graph_plans_torch(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk, split)
+                                        split=split, dw_tiles=dw_tiles, paths=paths)
+    return build_graph_plans_torch(edge_index, edge_type, n_nodes, num_relations, tile, aggr, fwd_range, bwd_range, chunk, split,
+                                   paths=paths)
 
 
 def balanced_ranges(counts_per_tile: Tensor, world: int, tile: int, n_nodes: int):
@@ -532,23 +560,28 @@ _CACHE_MAX_BYTES = int(float(_os.environ.get("RGCN_PLAN_CACHE_GB", "48")) * (1 <
 
 def _plans_nbytes(plans) -> int:
     pieces = getattr(plans, "pieces", None) or [plans]
-    return sum(p.fwd.nbytes() + p.bwd.nbytes() + (p.dw.nbytes() if getattr(p, "dw", None) is not None else 0) for p in pieces)
+    return sum(sum(q.nbytes() for q in (p.fwd, p.bwd, getattr(p, "dw", None), getattr(p, "ep_fwd", None), getattr(p, "ep_bwd", None))
+                   if q is not None) for p in pieces)
 
 
 def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,
                        tile: int, aggr: str, builder=None, extra_key=(), chunk: int = CHUNK, split: bool = False,
-                       dw_tiles: bool = False) -> GraphPlans:
+                       dw_tiles: bool = False, paths=("ring", "ring"), widths: Optional[Tuple[int, int]] = None) -> GraphPlans:
     """LRU over (edge tensors' identity, layout): at most ``_CACHE_MAX`` entries and ``RGCN_PLAN_CACHE_GB`` (48) GiB of
     plan arrays (4.3 GB per 100M edges), least recently used evicted first."""
     key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
-           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr, bool(split), bool(dw_tiles)) + tuple(extra_key)
+           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr, bool(split), bool(dw_tiles),
+           paths if isinstance(paths, str) else tuple(paths), widths) + tuple(extra_key)
     hit = _CACHE.pop(key, None)
     if hit is not None:
         _CACHE[key] = hit           # most recently used last
         return hit[0]
     if builder is None:
+        if paths == "auto":      # per direction: tile kernels or the edge-parallel path (eplan.choose_path), decided once per graph
+            from .eplan import decide_paths
+            paths = decide_paths(edge_index, n_nodes, num_relations, widths[0], widths[1], tile, chunk)
         plans = build_graph_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split,
-                                  dw_tiles=dw_tiles)
+                                  dw_tiles=dw_tiles, paths=paths)
     else:
         plans = builder()
     nbytes = _plans_nbytes(plans)

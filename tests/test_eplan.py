@@ -1,0 +1,106 @@
+"""Host logic of the edge-parallel path (scaling_rgcn_training_amd/eplan.py): the relation-major units and the
+destination-major sum levels reproduce the layer when walked the way csrc/rgcn_ep.hip walks them.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rgcn_oracle as O
+from scaling_rgcn_training_amd import eplan as E, plan as P
+from tests.plan_emulator import emulate_dw
+
+
+def emulate_ep(ep, x, w_all, bias=None):
+    """numpy twin of rgcn_ep_transform + rgcn_ep_segment_sum in float64"""
+    z = np.zeros((ep.n_units * 64, w_all.shape[2]))
+    src, sw = ep.slot_src.numpy(), ep.slot_w.numpy().astype(np.float64)
+    xr = np.concatenate([x, np.zeros((1, x.shape[1]))], 0)              # padding slots gather the row one past the end
+    rel = np.repeat(ep.unit_rel.numpy(), 64)
+    cnt = ep.unit_cnt.numpy()
+    used = (np.arange(64)[None, :] < cnt[:, None]).reshape(-1)            # slots of the row tiles the kernel multiplies
+    for r in range(w_all.shape[0]):
+        m = (rel == r) & used
+        z[m] = (xr[src[m]] @ w_all[r]) * sw[m][:, None]
+    z[~used] = np.nan                                                     # never written by the kernel, never read by the sums
+    cur = z
+    for ptr, idx, n_out in ep.levels:
+        ptr = ptr.numpy()
+        ii = idx.numpy() if idx is not None else np.arange(int(ptr[-1]))
+        cur = np.stack([cur[ii[ptr[i]:ptr[i + 1]]].sum(0) for i in range(n_out)]) if n_out else np.zeros((0, cur.shape[1]))
+    return cur + (0 if bias is None else bias)
+
+
+def _check_units(ep, n_real_rows):
+    assert ep.n_rows == n_real_rows
+    valid = ep.slot_src.view(-1, 64) < ep.n_nodes
+    nvalid = valid.sum(1)
+    assert torch.all(valid == (torch.arange(64)[None, :] < nvalid[:, None]))                  # real slots are a prefix of a unit
+    assert torch.all(ep.unit_cnt == (nvalid + 15) // 16 * 16) and torch.all(nvalid > 0)
+    assert torch.all(ep.unit_rel[1:] >= ep.unit_rel[:-1])                                    # relation-major
+    full = nvalid == 64
+    last_of_rel = torch.cat([ep.unit_rel[1:] != ep.unit_rel[:-1], torch.tensor([True])])
+    assert torch.all(full | last_of_rel), "only the last unit of a relation is padded"
+    assert torch.all(ep.slot_w.view(-1, 64)[~valid] == 0) and torch.all(ep.slot_row.view(-1, 64)[~valid] == ep.n_owned)
+    # level 0 reads every real slot exactly once; every level's output count feeds the next; the last one is the nodes
+    ptr0, idx0, _ = ep.levels[0]
+    assert sorted(idx0.tolist()) == torch.nonzero(valid.view(-1)).view(-1).tolist()
+    n_in = idx0.numel()
+    for ptr, idx, n_out in ep.levels:
+        assert int(ptr[0]) == 0 and int(ptr[-1]) == n_in and ptr.numel() == n_out + 1 and torch.all(ptr[1:] >= ptr[:-1])
+        n_in = n_out
+    assert ep.levels[-1][2] == ep.n_owned
+
+
+@pytest.mark.parametrize("piece", [E.PIECE, 8])
+def test_edge_plan_walk_matches_golden(golden, piece):
+    if str(golden["mode"]) != "full":
+        pytest.skip("plan is weight-mode independent")
+    f = lambda k: torch.from_numpy(golden[k])
+    n, r = int(golden["num_nodes"]), int(golden["num_relations"])
+    ei, et = f("edge_index").long(), f("edge_type").long()
+    w = P.edge_weights(ei[0], ei[1], et, r)
+    fwd = E.build_edge_plan(ei[0], ei[1], et, w, n, r, piece=piece)
+    bwd = E.build_edge_plan(ei[1], ei[0], et, w, n, r, piece=piece)
+    distinct = int(torch.unique((ei[0] * n + ei[1]) * r + et).numel())
+    for ep in (fwd, bwd):
+        _check_units(ep, distinct + n)
+        assert max(int((p[1:] - p[:-1]).max()) for p, _, _ in ep.levels) <= piece or len(ep.levels) == 1
+    if piece == 8 and fwd.max_rows_per_dst > 8:
+        assert len(fwd.levels) >= 2
+    w_all = np.concatenate([golden["weight"], golden["root"][None]], 0).astype(np.float64)
+    out = emulate_ep(fwd, golden["x"].astype(np.float64), w_all, golden["bias"])
+    np.testing.assert_allclose(out, golden["out"], rtol=1e-6, atol=1e-6)
+    dx = emulate_ep(bwd, golden["dout"].astype(np.float64), np.transpose(w_all, (0, 2, 1)))
+    np.testing.assert_allclose(dx, golden["d_x"], rtol=1e-6, atol=1e-6)
+    # the units as the weight-gradient kernels' walk (plan layout 2)
+    dw = emulate_dw(fwd.as_tile_plan(), golden["x"], golden["dout"], w_all.shape[0], w_all.shape[1], w_all.shape[2])
+    np.testing.assert_allclose(dw[:-1], golden["d_wfull"], rtol=1e-6, atol=1e-6)
+
+
+def test_edge_plan_owned_range_and_empty_graph():
+    n, e, r = 500, 3000, 4
+    ei, et = O.synthetic_graph(n, e, r, seed=3)
+    w = P.edge_weights(ei[0], ei[1], et, r)
+    full = E.build_edge_plan(ei[0], ei[1], et, w, n, r)
+    part = E.build_edge_plan(ei[0], ei[1], et, w, n, r, node_begin=128, node_end=320)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, 5, generator=g).double().numpy()
+    w_all = torch.randn(r + 1, 5, 3, generator=g).double().numpy()
+    np.testing.assert_allclose(emulate_ep(part, x, w_all), emulate_ep(full, x, w_all)[128:320], rtol=1e-12, atol=1e-12)
+    none = E.build_edge_plan(ei[0][:0], ei[1][:0], et[:0], w[:0], n, r)
+    _check_units(none, n)                                    # the root pseudo edges alone
+    np.testing.assert_allclose(emulate_ep(none, x, w_all), x @ w_all[r], rtol=1e-12, atol=1e-12)
+
+
+def test_choose_path_picks_the_edge_parallel_path_for_the_reference_shapes():
+    """model/modelTrainer.py:78,92: AIFB 89 relation ids on 8,243 nodes, MUTAG 45 on 23,644, AM ~267 on 1.5M -- few tiles,
+    a chunk per (tile, relation); a hub's tile walked by one workgroup.  The headline graph and its ladder stay on the tile
+    kernels (Z written and read once costs more than it saves there)."""
+    assert E.choose_path(8_243, 49_838, 89, 63, 16, 512, 64, 12_000) == "ep"
+    assert E.choose_path(23_644, 148_000, 45, 63, 16, 512, 64, 3_000) == "ep"
+    assert E.choose_path(1_500_000, 6_000_000, 267, 32, 32, 352, 64, 2_000) == "ep"
+    assert E.choose_path(10_000_000, 100_000_000, 32, 64, 64, 224, 128, 3_000) == "ring"
+    assert E.choose_path(1_000_000, 10_000_000, 32, 64, 64, 352, 128, 4_000) == "ring"
+    assert E.choose_path(100_000, 1_000_000, 32, 64, 64, 352, 128, 4_000) == "ring"
+    assert E.choose_path(10_000_000, 100_000_000, 32, 64, 64, 224, 128, 66_000_000) == "ep"       # Zipf hubs: two thirds of the edges in one tile
+    ei = torch.stack([torch.randint(0, 8243, (49838,)), torch.randint(0, 8243, (49838,))])
+    assert E.decide_paths(ei, 8243, 89, 63, 16, 512, 64) == ("ep", "ep")

@@ -1,0 +1,159 @@
+"""Parity of the edge-parallel path (csrc/rgcn_ep.hip: rgcn_ep_transform + rgcn_ep_segment_sum) against the float64 oracle,
+through the raw C ABI and through the drop-in module (path selection, weight gradients on the dense relation-major units)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rgcn_oracle as O
+from oracle.tolerance import abs_condition, assert_close, cpu32_reference
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    from scaling_rgcn_training_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=None, flags=0):
+    """forward, dX (edge-parallel kernels) and dW / dRoot / db (relation-major kernels on the plan's dense units)"""
+    from scaling_rgcn_training_amd import _lib, eplan as E, plan as P
+    from scaling_rgcn_training_amd.conv import _rows16, _round4
+    din, dout = w.shape[1], w.shape[2]
+    eid, etd = ei.to(dev), et.to(dev)
+    wgt = P.edge_weights(eid[0], eid[1], etd, r)
+    kw = {} if piece is None else {"piece": piece}
+    fwd = E.build_edge_plan(eid[0], eid[1], etd, wgt, n, r, **kw)
+    bwd = E.build_edge_plan(eid[1], eid[0], etd, wgt, n, r, **kw)
+    xd, gd = _rows16(x.to(dev), din), _rows16(dg.to(dev), dout)
+    wd, rd = w.to(dev).contiguous(), None if root is None else root.to(dev).contiguous()
+    bd = None if bias is None else bias.to(dev).contiguous()
+    out = torch.full((n, _round4(dout)), float("nan"), device=dev)
+    _lib.ep_layer(fwd, xd, din, _lib.pack_weights(wd, rd, False), bd, out, dout, 0, None, flags)
+    dx = torch.full((n, _round4(din)), float("nan"), device=dev)
+    _lib.ep_layer(bwd, gd, dout, _lib.pack_weights(wd, rd, True), None, dx, din, 0, None, flags)
+    dw = torch.full((r, din, dout), float("nan"), device=dev)
+    dr = torch.full((din, dout), float("nan"), device=dev)
+    db = torch.full((dout,), float("nan"), device=dev)
+    _lib.bwd_dw(_lib.plan_struct(fwd.as_tile_plan()), xd, din, gd, dout, dw, dr, db, flags)
+    torch.cuda.synchronize()
+    return (out[:, :dout].cpu().numpy(), dx[:, :din].cpu().numpy(), dw.cpu().numpy(), dr.cpu().numpy(), db.cpu().numpy()), fwd
+
+
+def _check(res, ref, gr, x, ei, et, w, root, bias, dg, tag):
+    out, dx, dw, dr, db = res
+    c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
+    o32, g32 = cpu32_reference(x, ei, et, w, root, bias, dg)
+    assert_close(out, ref, c_out, "ep out" + tag, cpu32=o32)
+    assert_close(dx, gr["x"], c["x"], "ep d_x" + tag, cpu32=g32["x"])
+    assert_close(dw, gr["weight"], c["weight"], "ep d_weight" + tag, cpu32=g32["weight"])
+    assert_close(dr, gr["root"], c["root"], "ep d_root" + tag, cpu32=g32["root"])
+    assert_close(db, gr["bias"], c["bias"], "ep d_bias" + tag, cpu32=g32["bias"])
+
+
+def test_ep_matches_golden(dev, golden):
+    """the topologies the reference ships (TEST graph, AIFB / MUTAG summaries: hubs of in-degree up to 11,825)"""
+    if str(golden["mode"]) != "full":
+        pytest.skip("weight modes go through the module (test_gpu_shapes)")
+    f = lambda k: torch.from_numpy(golden[k])
+    n, r = int(golden["num_nodes"]), int(golden["num_relations"])
+    res, ep = _ep_layer(dev, f("edge_index").long(), f("edge_type").long(), n, r, f("x"), f("weight"), f("root"), f("bias"), f("dout"))
+    x, dg = f("x"), f("dout")
+    ei, et = f("edge_index").long(), f("edge_type").long()
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), golden["weight"], golden["root"], golden["bias"], dg.numpy())
+    _check(res, ref, gr, x, ei, et, f("weight"), f("root"), f("bias"), dg, f" [golden n{n}]")
+
+
+@pytest.mark.parametrize("n,e,r,din,dout,skew,piece,flags", [
+    (8243, 49838, 89, 63, 16, False, None, 0),          # AIFB shape
+    (3000, 40000, 45, 16, 7, True, 32, 0),              # second layer of the reference's models (hidden 16 -> classes), hubs in levels
+    (5000, 120000, 267, 32, 32, False, None, 0),        # AM-like: more relations than rows per tile
+    (2000, 150000, 5, 64, 64, True, 64, 0),             # hubs of thousands of rows: three levels
+    (700, 9000, 3, 100, 128, False, None, 0),           # 128-wide: weight fragments reloaded per row tile
+    (700, 9000, 3, 128, 33, True, 16, 1),               # RGCN_FLAG_POINTER_GATHER: 64-bit pointer gathers
+    (40, 0, 2, 8, 8, False, None, 0),                   # no edges: the root pseudo edges alone
+])
+def test_ep_matches_oracle(dev, n, e, r, din, dout, skew, piece, flags):
+    ei, et = O.synthetic_graph(n, max(e, 1), r, seed=n + r, skew=skew)
+    if e == 0:
+        ei, et = ei[:, :0], et[:0]
+    else:
+        ei[:, 10:40] = ei[:, 50:80]            # duplicate triples
+        et[10:40] = et[50:80]
+    w, root, bias = O.synthetic_params(r, din, dout, seed=3)
+    g = torch.Generator().manual_seed(5)
+    bias = torch.randn(dout, generator=g) * 0.1
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    res, ep = _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=piece, flags=flags)
+    if piece is not None and ep.max_rows_per_dst > piece:
+        assert len(ep.levels) >= 2
+    _check(res, ref, gr, x, ei, et, w, root, bias, dg, f" [n{n} r{r} {din}->{dout}]")
+    again, _ = _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=piece, flags=flags)
+    assert all(np.array_equal(a, b) for a, b in zip(res, again)), "bit-reproducible"
+
+
+@pytest.mark.parametrize("act", [None, "relu", "sigmoid"])
+def test_ep_through_the_module_matches_the_tile_kernels(dev, act):
+    """``RGCNConv.path``: 'auto' picks the edge-parallel path on an AIFB-shaped graph; pinned 'ep' and pinned 'ring' agree
+    on the output and all four gradients (fused activation in the store, ReLU mask of the input in the dX store)."""
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    from scaling_rgcn_training_amd.plan import clear_plan_cache
+    n, e, r = 8243, 49838, 89
+    ei, et = O.synthetic_graph(n, e, r, seed=11, skew=True)
+    g = torch.Generator().manual_seed(2)
+    x = torch.relu(torch.randn(n, 63, generator=g))
+    dg = torch.randn(n, 16, generator=g)
+    eid, etd = ei.to(dev), et.to(dev)
+    res = {}
+    for path in ("auto", "ep", "ring"):
+        torch.manual_seed(0)
+        conv = RGCNConv(63, 16, r).to(dev)
+        conv.path = path
+        with torch.no_grad():
+            conv.bias.uniform_(-0.1, 0.1)
+        xd = x.to(dev).requires_grad_(True)
+        out = conv(xd, eid, etd, _activation=act, _input_relu=True)
+        plans = conv._plans(xd, eid, etd)
+        assert (plans.ep_fwd is not None) == (path != "ring") and (plans.ep_bwd is not None) == (path != "ring")
+        out.backward(dg.to(dev))
+        res[path] = [t.detach().cpu().numpy() for t in (out, xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad)]
+        clear_plan_cache()
+    for a, b in zip(res["auto"], res["ep"]):
+        assert np.array_equal(a, b)
+    for name, a, b in zip(("out", "d_x", "d_weight", "d_root", "d_bias"), res["ep"], res["ring"]):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(b).max())), err_msg=name)
+
+
+def test_ep_layer_step_is_hipgraph_capturable(dev):
+    """the edge-parallel path allocates through torch only and never synchronises: a forward + backward captures as it is and
+    the replay reproduces the eager step bit for bit"""
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    n, e, r = 3000, 20000, 45
+    ei, et = O.synthetic_graph(n, e, r, seed=5)
+    eid, etd = ei.to(dev), et.to(dev)
+    torch.manual_seed(1)
+    conv = RGCNConv(63, 16, r).to(dev)
+    conv.path = "ep"
+    x = torch.randn(n, 63, device=dev).requires_grad_(True)
+    dg = torch.randn(n, 16, device=dev)
+    conv(x, eid, etd).backward(dg)                    # plans, allocator pools
+    eager = [t.detach().clone() for t in (x.grad, conv.weight.grad, conv.root.grad)]
+    x.grad = None
+    conv.zero_grad(set_to_none=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = conv(x, eid, etd)
+            out.backward(dg)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, (x.grad, conv.weight.grad, conv.root.grad)):
+        assert torch.equal(a, b)
