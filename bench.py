@@ -62,7 +62,10 @@ HEADLINE = (10_000_000, 100_000_000, 32, 64)
 # shipped; AM: BASELINE.json configs[2], hidden 32, basis decomposition B = 30)
 LADDER = (("100k/1M", 100_000, 1_000_000, 32, 64, 64, None), ("1M/10M", 1_000_000, 10_000_000, 32, 64, 64, None),
           ("AIFB shape 63->16", 8_243, 49_838, 89, 63, 16, None), ("MUTAG shape 63->16", 23_644, 148_000, 45, 63, 16, None),
-          ("AM-like 32->32 B=30", 1_500_000, 6_000_000, 267, 32, 32, 30))
+          ("AM-like 32->32 B=30", 1_500_000, 6_000_000, 267, 32, 32, 30),
+          # SURVEY.md 8d "skew" variant at the headline size: dst ~ Zipf(1.2)-tailed mod N (KG hubs: node 0 receives 13 % of the
+          # edges, the first 224 nodes two thirds); the forward takes the edge-parallel path, dX the tile kernel
+          ("10M/100M skew", 10_000_000, 100_000_000, 32, 64, 64, None))
 CPU_RUNG = ("1M/10M", 1_000_000, 10_000_000)
 
 
@@ -515,9 +518,15 @@ def main():
             ladder = [{"rung": "10M/100M", "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
                        "gpu_ms_per_step": rec["ms_per_step_median"], "gpu_edges_per_s": e / (rec["ms_per_step_median"] * 1e-3)}]
             for name, ln, le, lr, lin, lout, nb in LADDER:
-                ms, ps_, msg, st = gpu_rung(ln, le, lr, lin, lout, dev, graph=le <= 1_000_000, num_bases=nb)
+                skew = "skew" in name
+                ms, ps_, msg, st = gpu_rung(ln, le, lr, lin, lout, dev, graph=le <= 1_000_000, num_bases=nb, skew=skew,
+                                            steps=10 if skew else 20, warmup=3 if skew else 5)
                 ladder.append({"rung": name, "nodes": ln, "edges": le, "relations": lr, "in": lin, "out": lout,
                                "gpu_ms_per_step": ms, "gpu_edges_per_s": le / (ms * 1e-3), "plan_build_s": ps_, "plan": st})
+                if skew:      # its own step-level roofline: the same algorithmic bytes as the uniform graph of that size
+                    sb = sum(algorithmic_bytes(le, ln, lr, lin, lout).values())
+                    ladder[-1]["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": sb, "achieved": sb / (ms * 1e-3) / 1e9,
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 if nb is not None:
                     ladder[-1]["num_bases"] = nb
                 if msg is not None:

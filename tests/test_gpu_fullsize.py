@@ -13,18 +13,43 @@ pytestmark = pytest.mark.gpu
 N, E, R, D = 10_000_000, 100_000_000, 32, 64
 
 
-@pytest.fixture(scope="module")
-def big():
+@pytest.fixture(scope="module", params=["uniform", "skew"])
+def big(request):
+    """uniform: SURVEY.md 8d's headline inputs; skew: its 'skew' variant (dst ~ Zipf(1.2)-tailed mod N: node 0 receives 13 % of
+    the edges, the first 224 nodes two thirds) -- the module's forward then takes the edge-parallel path, dX the tile kernel."""
     import bench
     from scaling_rgcn_training_amd.conv import RGCNConv
+    from scaling_rgcn_training_amd.plan import clear_plan_cache
+    clear_plan_cache()
+    torch.cuda.empty_cache()
     dev = torch.device("cuda:0")
-    ei, et, x, dg, weight, root = bench.synthetic_on_device(N, E, R, D, D, dev)
+    ei, et, x, dg, weight, root = bench.synthetic_on_device(N, E, R, D, D, dev, skew=request.param == "skew")
     conv = RGCNConv(D, D, R).to(dev)
     with torch.no_grad():
         conv.weight.copy_(weight)
         conv.root.copy_(root)
         conv.bias.copy_(torch.linspace(-0.5, 0.5, D, device=dev))
-    return dict(dev=dev, ei=ei, et=et, x=x, dg=dg, conv=conv)
+    return dict(dev=dev, ei=ei, et=et, x=x, dg=dg, conv=conv, kind=request.param)
+
+
+def _row_reference_on_device(big, row):
+    """float64 forward value (and its condition number) of ONE output row with any number of in-edges, by plain torch ops on
+    the device: per relation the sum of the gathered rows / count, times W_r; + x[row] @ root + bias."""
+    ei, et, conv, x = big["ei"], big["et"], big["conv"], big["x"]
+    sel = torch.nonzero(ei[1] == row).squeeze(1)
+    s, t = ei[0][sel], et[sel]
+    c = torch.bincount(t, minlength=R).double().clamp(min=1.0)
+    h = torch.zeros(R, D, dtype=torch.float64, device=x.device)
+    ha = torch.zeros_like(h)
+    for lo in range(0, int(sel.numel()), 1 << 22):                     # 4M rows at a time: 2 GiB of float64 rows
+        xs = x[s[lo:lo + (1 << 22)]].double()
+        h.index_add_(0, t[lo:lo + (1 << 22)], xs)
+        ha.index_add_(0, t[lo:lo + (1 << 22)], xs.abs())
+    w, root, b = conv.weight.detach().double(), conv.root.detach().double(), conv.bias.detach().double()
+    own = x[row].double()
+    val = torch.einsum("rk,rkn->n", h / c[:, None], w) + own @ root + b
+    cnd = torch.einsum("rk,rkn->n", ha / c[:, None], w.abs()) + own.abs() @ root.abs() + b.abs()
+    return val.cpu().numpy(), cnd.cpu().numpy(), int(sel.numel())
 
 
 def _sample_reference(big, rows, direction):
@@ -77,10 +102,24 @@ def test_full_size_sampled_rows_match_oracle(big):
     torch.cuda.synchronize()
     g = torch.Generator().manual_seed(7)
     rows = torch.randint(0, N, (96,), generator=g).unique().tolist() + [0, N - 1, 383, 384]
+    if big["kind"] == "skew":      # the row-by-row reference loop takes rows of ordinary in-degree; the hubs are checked below
+        deg_rows = torch.bincount(big["ei"][1], minlength=N)[torch.as_tensor(rows, device=big["dev"])].tolist()
+        rows = [r for r, dgr in zip(rows, deg_rows) if dgr <= 5000]
     ref, cond = _sample_reference(big, rows, "out")
     assert_close(out[rows].detach().cpu().numpy(), ref, cond, "out rows")
     refx, condx = _sample_reference(big, rows, "dx")
     assert_close(xg.grad[rows].cpu().numpy(), refx, condx, "dX rows")
+    if big["kind"] == "skew":
+        # the ten destinations with the most in-edges (millions of rows each: the per-destination sums go through levels)
+        from scaling_rgcn_training_amd.plan import cached_graph_plans
+        plans = conv._plans(xg, big["ei"], big["et"])
+        assert plans.ep_fwd is not None and len(plans.ep_fwd.levels) >= 3, "the hub graph's forward runs the edge-parallel path"
+        deg = torch.bincount(big["ei"][1], minlength=N)
+        hubs = torch.topk(deg, 10).indices.tolist()
+        for h in hubs:
+            val, cnd, n_in = _row_reference_on_device(big, h)
+            assert_close(out[h].detach().cpu().numpy()[None], val[None], cnd[None], f"hub row {h} ({n_in} in-edges)")
+        del deg
     big["out"], big["dx"] = out.detach(), xg.grad
     big["dw"], big["droot"], big["dbias"] = conv.weight.grad.clone(), conv.root.grad.clone(), conv.bias.grad.clone()
     # ---- weight gradients at full size, against float64 on the device with plain torch ops (independent of the

@@ -13,7 +13,8 @@ def child():
     for name, n, e, r, din, dout, nb in bench.LADDER:
         if want and not any(w in name for w in want):
             continue
-        ms, plan_s, msg, st = bench.gpu_rung(n, e, r, din, dout, dev, graph=e <= 8_000_000, num_bases=nb)
+        ms, plan_s, msg, st = bench.gpu_rung(n, e, r, din, dout, dev, graph=e <= 8_000_000, num_bases=nb, skew="skew" in name,
+                                             steps=10 if "skew" in name else 20)
         print(json.dumps({"rung": name, "path_env": os.environ.get("RGCN_PATH"), "ms": round(ms, 4),
                           "ms_hipgraph": None if msg is None else round(msg, 4), "plan_s": round(plan_s, 3), "plan": st}), flush=True)
 
