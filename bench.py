@@ -229,6 +229,11 @@ def main():
     ap.add_argument("--split-producers", dest="split_producers", action="store_true", default=None,
                     help="forward / dX on the bf16x3 kernel whose producer waves split the rows (fp32-equivalent; tile 224)")
     ap.add_argument("--no-split-producers", dest="split_producers", action="store_false")
+    ap.add_argument("--pieces", type=int, default=None,
+                    help="N > 1: gather pipeline depth (blocks per rank; default dist.PIECES = 4): the collective of piece s runs "
+                         "under the kernels of piece s + 1, the exposed tail is 1 / pieces of a gather")
+    ap.add_argument("--balance", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1: cut the node ranges by edge count (auto: only where equal node blocks differ by more than 5 %%)")
     args = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -257,6 +262,7 @@ def main():
     log(f"rank {rank}/{world}: generating {n} nodes / {e} edges / {r} relations on {torch.cuda.get_device_name(dev)}")
     ei, et, x, dg, weight, root = synthetic_on_device(n, e, r, d, d, dev)
     conv = RGCNConv(d, d, r).to(dev)
+    conv.path = "ring"        # the headline leg measures the tile kernels (eplan.choose_path picks them at this shape anyway)
     if args.split_producers is not None:
         conv.split_producers = bool(args.split_producers)
     with torch.no_grad():
@@ -264,7 +270,8 @@ def main():
         conv.root.copy_(root)
     del weight, root
     if world > 1:
-        rdist.attach(conv, n, e)
+        rdist.attach(conv, n, e, edge_index=ei, pieces=args.pieces or rdist.PIECES,
+                     balance={"auto": None, "on": True, "off": False}[args.balance])
     x.requires_grad_(True)
 
     torch.cuda.synchronize()
@@ -298,6 +305,7 @@ def main():
         for k in ("all_gather", "all_gather_bytes", "all_reduce", "all_reduce_bytes"):
             dctx.stats[k] = 0
         dctx.stats["wait_events"] = []
+        dctx.stats["dw_tiles_pieces"] = 0
         dctx.time_waits = True
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
@@ -319,8 +327,30 @@ def main():
     if dctx is not None:
         dctx.time_waits = False
         st = dctx.stats
-        wait_ms = sum(a.elapsed_time(b) for a, b in st["wait_events"]) / args.steps
-        comm = {"backend": backend, "pieces": dctx.pieces,
+        # one list of (start, end) HIP-event pairs per gather (forward and dX of every step), one pair per piece
+        per_piece = [0.0] * dctx.pieces
+        for evs_ in st["wait_events"]:
+            for i, (a, b) in enumerate(evs_):
+                per_piece[i] += a.elapsed_time(b)
+        n_gathers = max(1, len(st["wait_events"]))
+        wait_ms = sum(per_piece) / args.steps
+        bc = getattr(dctx, "block_costs", None)
+        rank_rows = bc.sum(0) if bc is not None else None        # rows (in- + out-edges + root rows) every rank walks per step
+        gather_bytes = n * d * 4 * (world - 1) / world             # what one gather moves INTO a rank
+        comm = {"backend": backend, "pieces": dctx.pieces, "cut": "uniform" if dctx.uniform else "balanced by edge count",
+                "rows_walked_per_rank": None if rank_rows is None else {
+                    "max": float(rank_rows.max()), "mean": float(rank_rows.mean()), "max_over_mean": float(rank_rows.max() / rank_rows.mean()),
+                    "per_block_max_over_mean": float(bc.max() / bc.mean())},
+                "d_weight_pieces_on_tile_major_kernel_per_step": st.get("dw_tiles_pieces", 0) / args.steps,
+                # which piece's gather the launch stream had to wait for (mean ms per gather; the last piece has no kernels
+                # left to hide under: its share is the exposed tail the pipeline depth trades against launch count)
+                "exposed_ms_per_piece": [v / n_gathers for v in per_piece],
+                # xGMI is point to point: a gather moves gather_bytes / (world - 1) over each of a rank's world - 1 links
+                "link_budget": {"bytes_per_link_per_gather": gather_bytes / max(1, world - 1),
+                                "ms_per_gather_at_153_GBps": gather_bytes / max(1, world - 1) / 153e9 * 1e3,
+                                "ms_per_gather_at_76_GBps": gather_bytes / max(1, world - 1) / 76e9 * 1e3,
+                                "gathers_per_step": 2,
+                                "measured_wait_ms_per_gather": sum(per_piece) / n_gathers},
                 "all_gather_per_step": st["all_gather"] / args.steps,
                 "all_gather_recv_bytes_per_step_per_rank": st["all_gather_bytes"] / args.steps,
                 "all_reduce_per_step": st["all_reduce"] / args.steps,
@@ -449,6 +479,8 @@ def main():
             fwd_diff = float((out_main - out_alt).abs().max())
             fwd_max = float(out_alt.abs().max())
             del out_main, out_alt
+            # the split-precision and the exact-fp32 kernels must agree far inside the 1e-5 tolerance on this very input
+            assert fwd_diff <= 2e-5 * max(1.0, fwd_max), f"forward kernels differ by {fwd_diff:.3e} (max |out| {fwd_max:.3e})"
             dw_diff = dw_max = None
             if psd is not None:      # d_weight by both forms of the tile-major kernel on the same operands
                 dw_b = torch.empty_like(dw)
@@ -456,6 +488,7 @@ def main():
                 _lib.bwd_dw_tiles(psd, plans.dw_walk, xd, d, dg, d, dw_b, conv.kernel_flags)
                 dw_diff, dw_max = float((dw - dw_b).abs().max()), float(dw_b.abs().max())
                 del dw_b
+                assert dw_diff <= 2e-5 * max(1.0, dw_max), f"d_weight kernels differ by {dw_diff:.3e} (max {dw_max:.3e})"
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
@@ -474,7 +507,9 @@ def main():
                    "forward_max_abs_diff_between_kernels": fwd_diff, "forward_max_abs": fwd_max,
                    "d_weight_max_abs_diff_between_kernels": dw_diff, "d_weight_max_abs": dw_max}
             log(f"alt ({'bf16x3 split' if conv.split_producers else 'exact-fp32'} forward / dX / dW): {ams:.2f} ms/step")
-        except Exception as err:      # the secondary leg must never take the headline record down
+        except AssertionError:
+            raise                      # two kernels of the product disagree: that IS a failed run
+        except Exception as err:      # (an allocation failure etc. in the secondary leg must not take the headline record down)
             log(f"alt leg skipped: {err!r}")
         finally:
             conv.split_producers = main_mode

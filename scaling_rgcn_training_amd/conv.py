@@ -82,27 +82,34 @@ def tile_for(in_channels: int, out_channels: int, n_nodes: int = 0, n_edges: int
 
 
 class DistContext:
-    """One process per GPU.  Output nodes are cut into ``pieces * world`` equal tile-aligned blocks, dealt
-    piece-major: block (s, r) = rows [(s * world + r) * piece_rows, +piece_rows) belongs to rank r.  A rank
-    computes piece s straight into its block of the gathered buffer and all-gathers the contiguous
-    super-block s asynchronously while it computes piece s + 1 (dist.py).  ``stats`` counts what the collectives
-    moved (bench.py reports it per step)."""
+    """One process per GPU.  Output nodes are cut into ``pieces * world`` tile-aligned blocks, dealt piece-major: block
+    (s, r) = rows [bounds[s * world + r], bounds[s * world + r + 1]) belongs to rank r.  A rank computes piece s straight into
+    its block of the gathered buffer and the blocks of super-block s travel asynchronously while it computes piece s + 1
+    (dist.py).  Two cuts:
+      * uniform (``piece_rows`` rows per block, the last blocks padded past the graph's end): one in-place
+        ``all_gather_into_tensor`` per piece -- the default wherever equal node blocks hold equal edge counts within 5 %;
+      * balanced (``dist.balanced_bounds``: blocks of about equal EDGE count): unequal blocks, gathered by one
+        broadcast per rank and piece (what an uneven all-gather is underneath).
+    ``stats`` counts what the collectives moved (bench.py reports it per step)."""
 
-    def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int):
+    def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int, bounds=None):
         self.group, self.rank, self.world = group, rank, world
-        self.piece_rows, self.pieces = piece_rows, pieces
+        self.pieces = pieces
+        self.uniform = bounds is None
+        self.piece_rows = piece_rows if self.uniform else None
+        self.bounds = [i * piece_rows for i in range(pieces * world + 1)] if self.uniform else [int(b) for b in bounds]
+        assert len(self.bounds) == pieces * world + 1
         self.stats = {"all_gather": 0, "all_gather_bytes": 0, "all_reduce": 0, "all_reduce_bytes": 0,
                       "wait_events": []}
-        self.time_waits = False     # bench.py: HIP events around the waits on the collectives
+        self.time_waits = False     # bench.py: HIP events around the waits on the collectives, piece by piece
 
     @property
     def total_rows(self) -> int:
-        return self.pieces * self.world * self.piece_rows
+        return self.bounds[-1]
 
     def block(self, s: int, r: Optional[int] = None) -> Tuple[int, int]:
         r = self.rank if r is None else r
-        b = (s * self.world + r) * self.piece_rows
-        return b, b + self.piece_rows
+        return self.bounds[s * self.world + r], self.bounds[s * self.world + r + 1]
 
     def node_range(self, s: int, n_nodes: int, r: Optional[int] = None) -> Tuple[int, int]:
         """owned node range of block (s, r), clipped to the graph; a block that lies wholly past the last node is
@@ -112,37 +119,58 @@ class DistContext:
             return b, b
         return b, min(e, n_nodes)
 
+    def src_rank(self, r: int) -> int:
+        """global rank of group rank r (broadcast sources are global ranks)"""
+        if self.group is None:
+            return r
+        return torch.distributed.get_global_rank(self.group, r)
+
 
 def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, device,
                    dtype: torch.dtype = torch.float32) -> Tensor:
-    """Run ``launch(plan, out_rows)`` for every piece this rank owns and all-gather the pieces, overlapping
-    the collective of piece s (RCCL's own stream) with the kernels of piece s + 1 (current stream).  The
-    all-gather is IN PLACE: this rank's block is already where the collective would put it (sendbuf ==
-    recvbuf + rank * count, the aliasing NCCL / RCCL document for in-place all-gather)."""
-    full = torch.empty(dctx.total_rows, ld, dtype=dtype, device=device)
+    """Run ``launch(plan, out_rows)`` for every piece this rank owns and gather the pieces, overlapping the collective of
+    piece s (RCCL's own stream) with the kernels of piece s + 1 (current stream).  Uniform cut: an IN-PLACE all-gather (this
+    rank's block is already where the collective would put it: sendbuf == recvbuf + rank * count, the aliasing NCCL / RCCL
+    document for in-place all-gather).  Balanced cut: every rank broadcasts its block of the piece in place."""
+    full = torch.empty(max(dctx.total_rows, n), ld, dtype=dtype, device=device)
     handles = []
-    w, pr = dctx.world, dctx.piece_rows
+    w = dctx.world
+    esz = full.element_size()
     for s_idx, plan in enumerate(plans_list):
-        b, _ = dctx.block(s_idx)
-        mine = full[b:b + pr]
+        b, e = dctx.block(s_idx)
+        mine = full[b:e]
         if plan.n_owned > 0:
             launch(plan, mine)
-        if plan.n_owned < pr:
+        if plan.n_owned < e - b:
             mine[plan.n_owned:].zero_()     # rows past the graph's end: defined bytes on the wire
-        sup = full[s_idx * w * pr:(s_idx + 1) * w * pr]
-        handles.append(torch.distributed.all_gather_into_tensor(sup, mine, group=dctx.group, async_op=True))
+        hs = []
+        if dctx.uniform:
+            sup = full[dctx.bounds[s_idx * w]:dctx.bounds[(s_idx + 1) * w]]
+            hs.append(torch.distributed.all_gather_into_tensor(sup, mine, group=dctx.group, async_op=True))
+            dctx.stats["all_gather_bytes"] += (w - 1) * (e - b) * ld * esz      # bytes this rank RECEIVES
+        else:
+            for r in range(w):
+                rb, re = dctx.block(s_idx, r)
+                if re > rb:
+                    hs.append(torch.distributed.broadcast(full[rb:re], src=dctx.src_rank(r), group=dctx.group, async_op=True))
+                    if r != dctx.rank:
+                        dctx.stats["all_gather_bytes"] += (re - rb) * ld * esz
+        handles.append(hs)
         dctx.stats["all_gather"] += 1
-        dctx.stats["all_gather_bytes"] += (w - 1) * pr * ld * full.element_size()      # bytes this rank RECEIVES
-    if dctx.time_waits and device.type == "cuda":
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for h in handles:
+    timed = dctx.time_waits and device.type == "cuda"
+    evs = []
+    for hs in handles:          # piece by piece: which piece's gather the launch stream had to wait for
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for h in hs:
             h.wait()
-        e1.record()
-        dctx.stats["wait_events"].append((e0, e1))
-    else:
-        for h in handles:
-            h.wait()
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            evs.append((e0, e1))
+    if timed:
+        dctx.stats["wait_events"].append(evs)
     return full[:n]
 
 
@@ -255,14 +283,25 @@ class _RGCNLayerFn(torch.autograd.Function):
             dw, droot, dbias = views(tiles_part)
         elif need_w or need_root or need_bias:
             # (an edge-parallel forward hands its dense relation-major units to the same kernels: GraphPlans.fwd_walk)
-            fplans = [plans.fwd_walk] if dctx is None else [p.fwd for p in plans.pieces]
+            pieces = [plans] if dctx is None else plans.pieces
+            pinned = flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)
             acc = None
-            for fp in fplans:
+            for pc in pieces:
+                fp = pc.fwd_walk
                 if fp.n_owned <= 0:
                     continue
                 part = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
                 pw, pr, pb = views(part)
-                _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[fp.node_begin:fp.node_end], dout, pw, pr, pb, flags)
+                b, e = fp.node_begin, fp.node_end
+                if (dctx is not None and need_w and getattr(pc, "dw", None) is not None and not pinned
+                        and _lib.buffer_addressable(n, xp.shape[1]) and _lib.buffer_addressable(e - b, gp.shape[1])):
+                    # a rank's piece on the tile-major kernel, as the single-GPU step (its root part: the piece's own rows)
+                    _lib.bwd_dw_tiles(_lib.plan_struct(pc.dw), pc.dw_walk, xp, din, gp[b:e], dout, pw, flags)
+                    if need_root or need_bias:
+                        _lib.bwd_dw_root(xp[b:e], din, gp[b:e], dout, pr, pb)
+                    dctx.stats["dw_tiles_pieces"] = dctx.stats.get("dw_tiles_pieces", 0) + 1
+                else:
+                    _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[b:e], dout, pw, pr, pb, flags)
                 acc = part if acc is None else acc.add_(part)
             if acc is None:
                 acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -392,21 +431,22 @@ class RGCNConv(nn.Module):
         e = int(edge_type.shape[0])
         tile, chunk = self.layout(n, e)
         split = self.team_layout and self._use_split_producers(chunk)       # plan layout 1 (team placement)
+        # the tile-major weight-gradient kernel: 64 x 64 layers with few relations on graphs large enough to fill it
+        # (it gathers through buffer descriptors only: above 2^24 rows / 4 GiB the relation-major kernels run)
+        from .plan import padded_width
+        dw_tiles = (self.dw_tiles and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64
+                    and self.num_relations <= 32 and e >= DW_TILES_MIN_EDGES and x.is_cuda
+                    and _lib.buffer_addressable(n, _round4(self.in_channels))
+                    and _lib.buffer_addressable(n, _round4(self.out_channels)))
         if self.dist is None:
-            # the tile-major weight-gradient kernel: 64 x 64 layers with few relations on graphs large enough to fill it
-            from .plan import padded_width
-            # (that kernel gathers through buffer descriptors only: above 2^24 rows / 4 GiB the relation-major kernels run)
-            dw_tiles = (self.dw_tiles and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64
-                        and self.num_relations <= 32 and e >= DW_TILES_MIN_EDGES and x.is_cuda
-                        and _lib.buffer_addressable(n, _round4(self.in_channels))
-                        and _lib.buffer_addressable(n, _round4(self.out_channels)))
-            paths = self.path if self.path in ("auto",) else ((self.path, self.path) if isinstance(self.path, str) else tuple(self.path))
+            paths = self.path if self.path == "auto" else ((self.path, self.path) if isinstance(self.path, str) else tuple(self.path))
             if not x.is_cuda:
                 paths = ("ring", "ring")
             return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split,
                                       dw_tiles=dw_tiles, paths=paths, widths=(self.in_channels, self.out_channels))
+        # edge-partitioned: every piece on the tile kernels (+ its own tile-major weight-gradient plan)
         from .dist import cached_rank_plans
-        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split)
+        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split, dw_tiles)
 
     def _use_split_producers(self, chunk: int) -> bool:
         from .plan import padded_width

@@ -690,7 +690,9 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     if (!sizes || !workspace || (g->num_edges > 0 && !w)) return RGCN_ERR_NULL;
     if (tile <= 0 || (tile % 16) != 0 || tile > 32768 || (chunk != 64 && chunk != 128)) return RGCN_ERR_PLAN;
     if (layout != 0 && !(layout == 1 && chunk == 128)) return RGCN_ERR_PLAN;
-    if (node_begin < 0 || node_end <= node_begin || node_end > g->num_nodes || (node_begin % tile) != 0) return RGCN_ERR_PLAN;
+    // (node_begin need not be a tile multiple: tiles count from node_begin.  Callers that want a rank's tiles to BE the
+    // single-rank tiles -- bit-identical outputs -- align their ranges themselves: scaling_rgcn_training_amd/dist.py)
+    if (node_begin < 0 || node_end <= node_begin || node_end > g->num_nodes) return RGCN_ERR_PLAN;
     hipStream_t s = (hipStream_t)stream;
     const u32 n_own = (u32)(node_end - node_begin), R = (u32)g->num_relations;
     const u64 E = (u64)g->num_edges;

@@ -118,6 +118,8 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     CHUNK = chunk  # noqa: N806  (shadows the module default inside this function)
     if node_end is None:
         node_end = n_nodes
+    if node_end <= node_begin:
+        return empty_plan(n_nodes, node_begin, num_relations, tile, chunk, gather.device, 1 if split else 0)
     if node_begin % tile != 0:
         raise ValueError("node_begin must be a multiple of the tile size")
     dev = gather.device
@@ -443,15 +445,22 @@ def build_graph_plans_torch(edge_index: Tensor, edge_type: Tensor, n_nodes: int,
     return gp
 
 
+def empty_plan(n_nodes: int, node_begin: int, num_relations: int, tile: int, chunk: int, device, layout: int = 0) -> TilePlan:
+    """the plan of an empty node range (dist.py: a block wholly past the last node, or squeezed out by a hub's block)"""
+    z = lambda dt=torch.int32: torch.zeros(0, dtype=dt, device=device)
+    return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_begin, num_relations=num_relations, tile=tile,
+                    chunk=chunk, n_tiles=0, n_chunks=0, n_edges=0, tile_ptr=torch.zeros(1, dtype=torch.int32, device=device),
+                    chunk_rel=z(), chunk_cnt=z(), chunk_tile=z(), chunk_flags=z(), rel_order=z(), slot_src=z(),
+                    slot_w=z(torch.float32), slot_dstl=None, slot_row=z(), slot_acc=z(), layout=layout)
+
+
 def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, tile: int, chunk: int,
-                 node_begin: int, node_end: int, ws, split: bool = False) -> TilePlan:
+                 node_begin: int, node_end: int, ws, split: bool = False, aligned: bool = True) -> TilePlan:
     from . import _lib
-    if node_end <= node_begin:           # a block wholly past the last node (dist.py): nothing to lay out
-        z = lambda dt=torch.int32: torch.zeros(0, dtype=dt, device=ws.device)
-        return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_begin, num_relations=num_relations, tile=tile,
-                        chunk=chunk, n_tiles=0, n_chunks=0, n_edges=0, tile_ptr=torch.zeros(1, dtype=torch.int32, device=ws.device),
-                        chunk_rel=z(), chunk_cnt=z(), chunk_tile=z(), chunk_flags=z(), rel_order=z(), slot_src=z(),
-                        slot_w=z(torch.float32), slot_dstl=None, slot_row=z(), slot_acc=z(), layout=int(split))
+    if node_end <= node_begin:           # nothing to lay out
+        return empty_plan(n_nodes, node_begin, num_relations, tile, chunk, ws.device, int(split))
+    if aligned and node_begin % tile != 0:       # forward / dX plans of a rank: its tiles must be the single-rank tiles
+        raise ValueError("node_begin must be a multiple of the tile size")
     ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, tile, chunk, ws, split)
     plan = TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, tile=tile,
                     chunk=chunk, n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None,
@@ -498,10 +507,12 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
             gp.ep_bwd = build_edge_plan(edge_index[1], edge_index[0], edge_type, w, n_nodes, num_relations, bb, be)
         else:
             gp.bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
-        if dw_tiles and paths[0] != "ep" and ranges is None and (fb, fe) == (0, n_nodes):
+        if dw_tiles and paths[0] != "ep" and fe > fb:
+            # the tile-major weight-gradient kernel's own layout of the same edges (a rank's piece: its node range need not
+            # be a multiple of THAT tile -- the sums of a partitioned d_weight differ in order from the single-rank ones anyway)
             t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
             if num_relations <= max_rel:
-                gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, 0, n_nodes, ws, False)
+                gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, fb, fe, ws, False, aligned=False)
                 gp.dw_walk = _lib.dw_tiles_walk(_lib.plan_struct(gp.dw), edge_type.device)
         out.append(gp)
     del keep

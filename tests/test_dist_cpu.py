@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret, n, e, tile, pieces):
+def _worker(rank, world, port, ret, n, e, tile, pieces, skew=False, balance=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,14 +31,19 @@ def _worker(rank, world, port, ret, n, e, tile, pieces):
     from scaling_rgcn_training_amd.conv import _gather_pieces
     from tests.plan_emulator import emulate_dw, emulate_spmm
     r, din, dout = 5, 8, 6
-    ei, et = O.synthetic_graph(n, e, r, seed=4)
+    ei, et = O.synthetic_graph(n, e, r, seed=4, skew=skew)
     w, root, bias = O.synthetic_params(r, din, dout, seed=4)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(n, din, generator=g).double()
     dg = torch.randn(n, dout, generator=g).double()
     w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0).astype(np.float64)
-    ctx = rdist.make_context(n, tile, pieces=pieces)
+    ctx = rdist.make_context(n, tile, pieces=pieces, edge_index=ei, balance=balance)
     assert ctx is not None and ctx.world == world and ctx.rank == rank
+    if balance or skew:
+        assert not ctx.uniform, "edge counts of equal node blocks differ by more than 5 %: the cut follows the edges"
+        assert all(b % tile == 0 for b in ctx.bounds[:-1]) and ctx.bounds[-1] == n and ctx.bounds == sorted(ctx.bounds)
+        uni = rdist.block_costs(rdist.tile_costs(ei, n, tile), [i * rdist.piece_rows(n, tile, world, ctx.pieces) for i in range(world * ctx.pieces + 1)], tile)
+        assert float(ctx.block_costs.max()) <= float(uni.max()), "never worse than the uniform cut"
     plans = rdist.rank_plans(ei, et, n, r, tile, "mean", ctx)
     assert len(plans.pieces) == ctx.pieces
     assert sum(p.fwd.n_edges for p in plans.pieces) <= e
@@ -75,11 +80,11 @@ def _worker(rank, world, port, ret, n, e, tile, pieces):
     dist.destroy_process_group()
 
 
-def _run(world, n, e, tile, pieces):
+def _run(world, n, e, tile, pieces, skew=False, balance=None):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, n, e, tile, pieces)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, n, e, tile, pieces, skew, balance)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -97,3 +102,28 @@ def test_two_rank_gloo_empty_trailing_blocks():
     in 2 x 4 blocks of 2 tiles -> blocks 5..7 lie (partly or wholly) past the last node (the case that raised
     'node_begin must be a multiple of the tile size' in round 1)."""
     _run(2, 637, 5000, 64, 4)
+
+
+def test_four_ranks_on_an_aifb_sized_graph():
+    """fewer tiles than world x pieces blocks want (ADVICE r1's failing case: AIFB at world 4): 8,243 nodes at tile 512 = 17
+    tiles -> the piece count drops to 4 tiles-per-rank's worth and trailing blocks are empty"""
+    _run(4, 8243, 49838, 512, 4)
+
+
+def test_eight_ranks_on_an_aifb_sized_graph():
+    _run(8, 8243, 49838, 512, 4)
+
+
+def test_four_ranks_edge_balanced_cut_on_a_hub_graph():
+    """dst ~ Zipf(1.2)-tailed (SURVEY.md 8d 'skew'): equal node blocks differ several-fold in edge count, so the cut follows the
+    prefix sum of the tiles' edge counts; unequal blocks are gathered by one broadcast per rank and piece; results still
+    bit-identical to the single-rank layer"""
+    _run(4, 6000, 60000, 64, 4, skew=True)
+
+
+def test_eight_ranks_edge_balanced_cut_on_a_hub_graph():
+    _run(8, 6000, 60000, 64, 3, skew=True)
+
+
+def test_two_ranks_balanced_cut_pinned_on_a_uniform_graph():
+    _run(2, 1000, 9000, 64, 3, balance=True)

@@ -32,9 +32,15 @@ def _worker(rank, world, port, ret, dw_direct):
     from scaling_rgcn_training_amd import _lib, dist as rdist
     from scaling_rgcn_training_amd.conv import RGCNConv
     dev = torch.device("cuda:0")
-    flags = _lib.FLAG_DW_DIRECT if dw_direct == "2" else _lib.FLAG_DW_RING   # pin the dW kernel on every piece
+    # "0" / "2": pin the relation-major dW kernel (ring / direct) on every piece; "tiles": the default of 64 x 64 layers on
+    # large graphs -- every piece on the tile-major kernel with its own T = 304 plan -- reached here by lowering the
+    # edge-count threshold; "skew": the same on a hub graph, whose cut follows the edge counts (unequal blocks, broadcasts)
+    from scaling_rgcn_training_amd import conv as C
+    flags = {"0": _lib.FLAG_DW_RING, "2": _lib.FLAG_DW_DIRECT}.get(dw_direct, 0)
+    if dw_direct in ("tiles", "skew"):
+        C.DW_TILES_MIN_EDGES = 1
     n, e, r, din, dout = 3000, 40000, 6, 64, 64
-    ei, et = O.synthetic_graph(n, e, r, seed=2)
+    ei, et = O.synthetic_graph(n, e, r, seed=2, skew=dw_direct == "skew")
     w, root, bias = O.synthetic_params(r, din, dout, seed=2)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(n, din, generator=g)
@@ -43,17 +49,22 @@ def _worker(rank, world, port, ret, dw_direct):
     def run(partitioned):
         conv = RGCNConv(din, dout, r).to(dev)
         conv.kernel_flags = flags
+        conv.path = "ring"          # (alone, the layer would take the edge-parallel path on the hub graph; the partition runs tile kernels)
         with torch.no_grad():
             conv.weight.copy_(w)
             conv.root.copy_(root)
             conv.bias.copy_(bias + 0.25)
         if partitioned:
-            rdist.attach(conv, n, e)
+            rdist.attach(conv, n, e, edge_index=ei)
             assert conv.dist is not None and conv.dist.world == world
+            assert conv.dist.uniform == (dw_direct != "skew")
         xd = x.to(dev).requires_grad_(True)
         out = conv(xd, ei.to(dev), et.to(dev))
         out.backward(dg.to(dev))
         torch.cuda.synchronize()
+        if partitioned and dw_direct in ("tiles", "skew"):
+            owned = sum(1 for pc in conv._plans(xd, ei.to(dev), et.to(dev)).pieces if pc.fwd.n_owned > 0)
+            assert conv.dist.stats.get("dw_tiles_pieces", 0) == owned > 0, "every piece's d_weight on the tile-major kernel"
         return (out.detach().cpu().numpy(), xd.grad.cpu().numpy(), conv.weight.grad.cpu().numpy(),
                 conv.root.grad.cpu().numpy(), conv.bias.grad.cpu().numpy())
 
@@ -76,7 +87,7 @@ def _worker(rank, world, port, ret, dw_direct):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dw_direct", ["0", "2"])
+@pytest.mark.parametrize("dw_direct", ["0", "2", "tiles", "skew"])
 def test_two_ranks_one_gpu_partitioned_layer_equals_single_rank(dw_direct):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
