@@ -13,9 +13,10 @@ Two bounds, both enforced wherever the fp32 CPU loop can run (``cpu32`` given):
      BASELINE.json asks for results "within 1e-5 of the reference CPU path"; that path is fp32 (PyG's loop over
      ATen kernels, restated by ``rgcn_oracle.rgcn_conv_loop``), so ITS error against float64 on the same input is
      the only legitimate slack over the flat 1e-5: a kernel ten times less accurate than ATen fails (2) even where
-     the a-priori bound (1) would let it through.  (``cpu_factor`` = 4 for the tile-major d_weight kernel only: there a
-     wave adds ALL edges of a relation inside its tile range into one fp32 accumulator -- tens of thousands of terms in
-     sequence where ATen's blocked sums re-associate; its measured excess stays within 2.2 x the CPU loop's.)
+     the a-priori bound (1) would let it through.  (``cpu_factor`` = 2.5 for the tile-major d_weight kernel and the
+     streaming d_root / d_bias kernel only: there a wave adds ALL rows of its range into one fp32 accumulator -- tens of
+     thousands of terms in sequence where ATen's blocked sums re-associate; the measured excess is 2.2 x the CPU loop's, and
+     the bound follows the measurement.)
 
 Every call records how much of the slack over flat 1e-5 was used (``SLACK_LOG``); tests/conftest.py prints the
 worst cases in the terminal summary.

@@ -125,7 +125,7 @@ def test_full_size_sampled_rows_match_oracle(big):
     # ---- weight gradients at full size, against float64 on the device with plain torch ops (independent of the
     # plan): d_bias = column sums of dOut, d_root = X^T dOut, d_weight[r] = H_r^T dOut for the first relation, the
     # last one and a random one (~3.1M edges each).  Criterion: the a-priori bound of oracle/tolerance.py (flat 1e-5
-    # + 4 u cond) AND no worse than the STOCK fp32 path on the same sums -- rocBLAS / ATen fp32 evaluations of the
+    # + 4 u cond) AND no worse than 2.5 x the STOCK fp32 path on the same sums (measured: d_weight 0.6 x, d_bias 2.0 x) -- rocBLAS / ATen fp32 evaluations of the
     # same products stand in for the reference's CPU loop, which cannot run at this size.
     from oracle.tolerance import SLACK_LOG
     dg, ei, et = big["dg"], big["ei"], big["et"]
@@ -136,20 +136,39 @@ def test_full_size_sampled_rows_match_oracle(big):
         flat = 1e-5 + 1e-5 * ref64.abs()
         assert torch.all(err <= flat + 4 * U * cond64), (name, float((err - flat - 4 * U * cond64).max()))
         excess, stock_err = float((err - flat).max()), float((stock32.double() - ref64).abs().max())
-        assert excess <= 4 * stock_err, f"{name}: excess over flat 1e-5 {excess:.3e} > 4 x the stock fp32 path's error {stock_err:.3e}"
+        assert excess <= 2.5 * stock_err, f"{name}: excess over flat 1e-5 {excess:.3e} > 2.5 x the stock fp32 path's error {stock_err:.3e}"
         SLACK_LOG.append((f"full-size {name}", excess, stock_err))
 
     check("d_bias", big["dbias"], dg.double().sum(0), dg.double().abs().sum(0), dg.sum(0))
     check("d_root", big["droot"], x.double().T @ dg.double(), x.double().abs().T @ dg.double().abs(), x.T @ dg)
     cnt = torch.bincount(ei[1] * R + et, minlength=N * R)
+    refs = {}
     for r in (0, R - 1, 13):
         idx = torch.nonzero(et == r).squeeze(1)
         s, d = ei[0][idx], ei[1][idx]
         we = 1.0 / cnt[d * R + r].double()
         h64 = x[s].double() * we[:, None]
         g64 = dg[d].double()
-        check(f"d_weight[{r}]", big["dw"][r], h64.T @ g64, h64.abs().T @ g64.abs(), (x[s] * we.float()[:, None]).T @ dg[d])
+        ref_r = h64.T @ g64
+        check(f"d_weight[{r}]", big["dw"][r], ref_r, h64.abs().T @ g64.abs(), (x[s] * we.float()[:, None]).T @ dg[d])
+        refs[r] = ref_r
         del h64, g64
+    plans = conv._plans(xg, ei, et)
+    if getattr(plans, "dw", None) is not None:
+        # The tile-major kernel in BOTH forms on the same plan, against float64.  The bf16 x 3 form is the
+        # less accurate one at this size -- not through its dropped ml / lm / ll products but because v_mfma_f32_16x16x32_bf16
+        # TRUNCATES its aligned addends next to a large accumulator (tools/probes/mfma_bf16_accumulate_bias.hip: the error is
+        # negative for both signs of the products; tools/debug/dw_split_error_probe.py: a mean signed error that grows
+        # linearly with the edges per slab, -7.5e-2 at 12M edges per relation, where the exact form's is +1.6e-4).  Measured
+        # ratio of the worst errors: 2.1; the bound follows the measurement, both forms stay inside the oracle bounds above.
+        from scaling_rgcn_training_amd import _lib
+        dw_s, dw_e = torch.empty_like(big["dw"]), torch.empty_like(big["dw"])
+        _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, x, D, dg, D, dw_s, _lib.FLAG_SPLIT_PRODUCERS)
+        _lib.bwd_dw_tiles(_lib.plan_struct(plans.dw), plans.dw_walk, x, D, dg, D, dw_e, 0)
+        for r, ref_r in refs.items():
+            es, ee = float((dw_s[r].double() - ref_r).abs().max()), float((dw_e[r].double() - ref_r).abs().max())
+            print(f"full-size d_weight[{r}]: worst error against float64, bf16 x 3 form {es:.3e}, exact-fp32 form {ee:.3e}, ratio {es / max(ee, 1e-30):.2f}")
+            assert es <= 2.5 * ee, f"d_weight[{r}]: bf16 x 3 form {es:.3e} vs exact-fp32 form {ee:.3e} against float64"
 
 
 def test_full_size_weight_gradients_linear_in_dout(big):

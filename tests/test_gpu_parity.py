@@ -412,7 +412,7 @@ def test_dw_tile_major_kernel(dev, n, e, r, skew, split):
     torch.cuda.synchronize()
     c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
     _, g32 = cpu32_reference(x, ei, et, w, root, bias, dg)
-    assert_close(dw.cpu().numpy(), gr["weight"], c["weight"], f"d_weight (tile-major) [n{n} r{r}]", cpu32=g32["weight"], cpu_factor=4.0)
+    assert_close(dw.cpu().numpy(), gr["weight"], c["weight"], f"d_weight (tile-major) [n{n} r{r}]", cpu32=g32["weight"], cpu_factor=2.5)
     assert_close(dr.cpu().numpy(), gr["root"], c["root"], f"d_root (root-only walk) [n{n} r{r}]", cpu32=g32["root"])
     assert_close(db.cpu().numpy(), gr["bias"], c["bias"], f"d_bias (root-only walk) [n{n} r{r}]", cpu32=g32["bias"])
     assert_close(dw.cpu().numpy(), dw0.cpu().numpy(), c["weight"], "tile-major vs relation-major d_weight")
@@ -443,8 +443,8 @@ def test_dw_root_streaming_kernel(dev, rows, din, dout):
     cond_r, cond_b = np.abs(x64).T @ np.abs(g64), np.abs(g64).sum(0)
     cpu_r = (x[:, :din].t() @ dg[:, :dout]).numpy()
     cpu_b = dg[:, :dout].sum(0).numpy()
-    assert_close(dr.cpu().numpy(), ref_r, cond_r, f"d_root (streaming kernel) [{rows}x{din}x{dout}]", cpu32=cpu_r, cpu_factor=4.0)
-    assert_close(db.cpu().numpy(), ref_b, cond_b, f"d_bias (streaming kernel) [{rows}x{din}x{dout}]", cpu32=cpu_b, cpu_factor=4.0)
+    assert_close(dr.cpu().numpy(), ref_r, cond_r, f"d_root (streaming kernel) [{rows}x{din}x{dout}]", cpu32=cpu_r, cpu_factor=2.5)
+    assert_close(db.cpu().numpy(), ref_b, cond_b, f"d_bias (streaming kernel) [{rows}x{din}x{dout}]", cpu32=cpu_b, cpu_factor=2.5)
     dr2, db2 = torch.empty_like(dr), torch.empty_like(db)
     _lib.bwd_dw_root(xd, din, gd, dout, dr2, None)
     _lib.bwd_dw_root(xd, din, gd, dout, None, db2)
@@ -483,6 +483,38 @@ def test_split_producers_kernel_matches_oracle(dev, n, e, r, tile, skew, teams):
     assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel
     again = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=tile, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS, split=teams)
     assert np.array_equal(res3[0], again[0]) and np.array_equal(res3[1], again[1])
+
+
+def test_split_kernels_on_extreme_magnitudes(dev):
+    """the bf16 x 3 kernels cut every fp32 operand into round-to-nearest bf16 pieces.  bf16 has fp32's exponent
+    range, so huge (1e30) and tiny (1e-30) finite values split exactly like ordinary ones and the split kernels agree with the
+    exact-fp32 kernels relative to the row's magnitude; fp32 denormals (1e-40) are flushed by both forms -- their
+    contributions are 1e-35 below the tolerance.  What differs is documented, not hidden: an Inf (or a finite value above
+    bf16's largest, 3.39e38) makes the high piece Inf and the residual NaN, so the rows such a value reaches come out NaN
+    where the exact kernel says +-Inf / NaN -- non-finite in both, finite and equal everywhere else."""
+    from scaling_rgcn_training_amd import _lib
+    n, e, r = 3000, 60000, 3
+    ei, et = O.synthetic_graph(n, e, r, seed=21)
+    w, root, bias = O.synthetic_params(r, 64, 64, seed=21)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, 64, generator=g)
+    dg = torch.randn(n, 64, generator=g)
+    x[10] *= 1e30
+    x[11] *= 1e-30
+    x[12] = 1e-40                                   # fp32 denormals
+    x[13, 5] = float("inf")
+    res3 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=224, chunk=128, flags=_lib.FLAG_SPLIT_PRODUCERS)
+    res1 = _abi_layer(dev, ei, et, n, r, x, w, root, bias, dg, tile=224, chunk=128)
+    out3, out1 = res3[0], res1[0]
+    reached = np.zeros(n, dtype=bool)               # rows the Inf reaches: node 13 itself and the destinations of its out-edges
+    reached[13] = True
+    reached[ei[1][ei[0] == 13].numpy()] = True
+    assert not np.isfinite(out3[reached]).all(axis=1).any() and not np.isfinite(out1[reached]).all(axis=1).any()
+    assert np.isfinite(out3[~reached]).all() and np.isfinite(out1[~reached]).all()
+    scale = np.maximum(1.0, np.abs(out1[~reached]).max(axis=1, keepdims=True))          # per row: 1e30-sized rows compare relatively
+    assert np.max(np.abs(out3[~reached] - out1[~reached]) / scale) <= 2e-5
+    # dX does not see x; finite and equal throughout
+    assert np.isfinite(res3[1]).all() and np.max(np.abs(res3[1] - res1[1])) <= 2e-5 * max(1.0, float(np.abs(res1[1]).max()))
 
 
 def test_split_producers_through_the_module(dev):
@@ -546,7 +578,7 @@ def test_tile_major_dw_through_the_module(dev, monkeypatch, split):
     _, g32 = cpu32_reference(x, ei, et, w, root, bias, dg)
     assert_close(out.detach().cpu().numpy(), ref, c_out, f"module out [{split}]")
     assert_close(xd.grad.cpu().numpy(), gr["x"], c["x"], f"module d_x [{split}]", cpu32=g32["x"])
-    assert_close(conv.weight.grad.cpu().numpy(), gr["weight"], c["weight"], f"module d_weight (tile-major) [{split}]", cpu32=g32["weight"], cpu_factor=4.0)
+    assert_close(conv.weight.grad.cpu().numpy(), gr["weight"], c["weight"], f"module d_weight (tile-major) [{split}]", cpu32=g32["weight"], cpu_factor=2.5)
     assert_close(conv.root.grad.cpu().numpy(), gr["root"], c["root"], f"module d_root (side stream) [{split}]", cpu32=g32["root"])
     assert_close(conv.bias.grad.cpu().numpy(), gr["bias"], c["bias"], f"module d_bias (side stream) [{split}]", cpu32=g32["bias"])
     assert torch.all(conv.weight.grad[r - 1] == 0)
