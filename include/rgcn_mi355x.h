@@ -172,6 +172,20 @@ size_t rgcn_packed_weight_floats(int num_relations, int din, int dout);
  * Replaces nothing in PyG (it indexes weight[i] directly); cost O(R' * din * dout) per call. */
 int rgcn_pack_weights(const float* weight, const float* root, int num_relations, int din, int dout,
                       int transpose, float* packed, void* stream);
+/* The same pack for PyG's two weight decompositions (BASELINE.json configs[2]: num_bases = 30),
+ * composed inside the packer -- [R', din, dout] is never materialised:
+ *   basis: W_r = sum_b comp[r, b] * bases[b], bases [B, din, dout], comp [R', B]  (torch: comp @ weight.view(B, -1));
+ *   block: W_r = blockdiag(blocks[r, 0 .. nb - 1]), blocks [R', nb, din / nb, dout / nb]. */
+int rgcn_pack_weights_basis(const float* bases, const float* comp, const float* root, int num_relations, int num_bases,
+                            int din, int dout, int transpose, float* packed, void* stream);
+int rgcn_pack_weights_block(const float* blocks, const float* root, int num_relations, int num_blocks, int din, int dout,
+                            int transpose, float* packed, void* stream);
+/* Gradients of the decomposition's parameters from the dense d_w [R', din, dout] that rgcn_bwd_dw / rgcn_bwd_dw_tiles
+ * produce (a scratch buffer, not an autograd tensor): d_bases[b] = sum_r comp[r, b] d_w[r], d_comp[r, b] = <d_w[r], bases[b]>
+ * (either may be NULL); d_blocks = the diagonal blocks of d_w.  Fixed summation orders: bit-reproducible. */
+int rgcn_basis_backward(const float* d_w, const float* bases, const float* comp, int num_relations, int num_bases, int din,
+                        int dout, float* d_bases, float* d_comp, void* stream);
+int rgcn_block_backward(const float* d_w, int num_relations, int num_blocks, int din, int dout, float* d_blocks, void* stream);
 
 /* Forward of RGCNConv.forward (aggr mean/sum folded into the plan's edge weights):
  *   out[i, :] = act(bias + sum_{slots scattering into i} w_e * x[src_e, :] @ W_{rel_e})   (root = rel R')

@@ -22,6 +22,7 @@ EXPORTS = (
     "rgcn_plan_workspace_bytes", "rgcn_edge_weights", "rgcn_plan_build_begin", "rgcn_plan_build_finish",
     "rgcn_dw_tiles_geometry", "rgcn_dw_tiles_walk", "rgcn_bwd_dw_tiles_workspace_bytes", "rgcn_bwd_dw_tiles",
     "rgcn_bwd_dw_root_workspace_bytes", "rgcn_bwd_dw_root", "rgcn_ep_transform", "rgcn_ep_segment_sum",
+    "rgcn_pack_weights_basis", "rgcn_pack_weights_block", "rgcn_basis_backward", "rgcn_block_backward",
 )
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
@@ -122,6 +123,14 @@ def load() -> C.CDLL:
     lib.rgcn_bwd_dw_root_workspace_bytes.argtypes = []
     lib.rgcn_bwd_dw_root.restype = i32
     lib.rgcn_bwd_dw_root.argtypes = [vp, i32, i32, vp, i32, i32, C.c_long, vp, sz, vp, vp, vp]
+    lib.rgcn_pack_weights_basis.restype = i32
+    lib.rgcn_pack_weights_basis.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.rgcn_pack_weights_block.restype = i32
+    lib.rgcn_pack_weights_block.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.rgcn_basis_backward.restype = i32
+    lib.rgcn_basis_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.rgcn_block_backward.restype = i32
+    lib.rgcn_block_backward.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.rgcn_ep_transform.restype = i32
     lib.rgcn_ep_transform.argtypes = [C.POINTER(RgcnEdgeUnits), vp, i32, i32, vp, vp, i32, i32, u32, vp]
     lib.rgcn_ep_segment_sum.restype = i32
@@ -188,6 +197,48 @@ def pack_weights(weight: torch.Tensor, root: Optional[torch.Tensor], transpose: 
         check(lib.rgcn_pack_weights(weight.data_ptr(), _ptr(root), r, din, dout, int(transpose),
                                     packed.data_ptr(), _stream(weight)), "rgcn_pack_weights")
     return packed
+
+
+def pack_weights_decomposed(weight: torch.Tensor, comp: Optional[torch.Tensor], root: Optional[torch.Tensor], num_relations: int,
+                            din: int, dout: int, transpose: bool) -> torch.Tensor:
+    """The pack of a layer's weights whatever their parametrisation (PyG RGCNConv): dense ``weight [R, in, out]``, basis
+    decomposition (``weight [B, in, out]`` + ``comp [R, B]``) or block-diagonal (``weight [R, nb, in/nb, out/nb]``).  The
+    decompositions are composed inside the packer: no [R, in, out] tensor exists."""
+    if comp is None and weight.dim() == 3:
+        return pack_weights(weight, root, transpose)
+    lib = load()
+    n = lib.rgcn_packed_weight_floats(num_relations, din, dout)
+    if n == 0:
+        raise RgcnLibraryError(f"unsupported layer widths {din}->{dout} (1..128 per side)")
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        if comp is not None:
+            check(lib.rgcn_pack_weights_basis(weight.data_ptr(), comp.data_ptr(), _ptr(root), num_relations, weight.shape[0], din, dout,
+                                              int(transpose), packed.data_ptr(), _stream(weight)), "rgcn_pack_weights_basis")
+        else:
+            check(lib.rgcn_pack_weights_block(weight.data_ptr(), _ptr(root), num_relations, weight.shape[1], din, dout,
+                                              int(transpose), packed.data_ptr(), _stream(weight)), "rgcn_pack_weights_block")
+    return packed
+
+
+def decomposed_weight_grads(d_w: torch.Tensor, weight: torch.Tensor, comp: Optional[torch.Tensor], need_weight: bool, need_comp: bool):
+    """(d_weight, d_comp) of the layer's own parameters from the dense ``d_w [R, in, out]`` scratch the weight-gradient kernels
+    wrote (rgcn_basis_backward / rgcn_block_backward)."""
+    lib = load()
+    r, din, dout = d_w.shape
+    with torch.cuda.device(d_w.device):
+        if comp is not None:
+            dv = torch.empty_like(weight) if need_weight else None
+            dc = torch.empty_like(comp) if need_comp else None
+            if need_weight or need_comp:
+                check(lib.rgcn_basis_backward(d_w.data_ptr(), weight.data_ptr(), comp.data_ptr(), r, weight.shape[0], din, dout,
+                                              _ptr(dv), _ptr(dc), _stream(d_w)), "rgcn_basis_backward")
+            return dv, dc
+        db = None
+        if need_weight:
+            db = torch.empty_like(weight)
+            check(lib.rgcn_block_backward(d_w.data_ptr(), r, weight.shape[1], din, dout, db.data_ptr(), _stream(d_w)), "rgcn_block_backward")
+        return db, None
 
 
 def fwd(ps: RgcnPlanStruct, x: torch.Tensor, din: int, packed: torch.Tensor,

@@ -179,17 +179,21 @@ class _RGCNLayerFn(torch.autograd.Function):
     into its store; backward: rgcn_bwd_dx on the transposed plan + rgcn_bwd_dw)."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, w_full: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
+    def forward(ctx, x: Tensor, weight: Tensor, comp: Optional[Tensor], root: Optional[Tensor], bias: Optional[Tensor],
                 plans: GraphPlans, dctx: Optional[DistContext], act: int, input_relu: bool, grad_premasked: bool,
-                flags: int):
+                flags: int, num_rel: int, dout: int):
+        # weight / comp: the layer's OWN parameters -- dense [R, in, out], bases [B, in, out] + comp [R, B], or blocks
+        # [R, nb, in / nb, out / nb]: a decomposition is composed inside the weight packer and differentiated from the dense
+        # d_W scratch of the weight-gradient kernels (rgcn_pack_weights_basis / _block, rgcn_basis_backward / rgcn_block_backward),
+        # so autograd never holds an [R, in, out] tensor (PyG materialises it on every call)
         n, din = x.shape
-        num_rel, _, dout = w_full.shape
         fp: Optional[TilePlan] = plans.fwd if dctx is None else None
         xp = _rows16(x, din)
-        wf = w_full.detach().float().contiguous()
+        wf = weight.detach().float().contiguous()
+        cp = None if comp is None else comp.detach().float().contiguous()
         rt = None if root is None else root.detach().float().contiguous()
         bs = None if bias is None else bias.detach().float().contiguous()
-        packed = _lib.pack_weights(wf, rt, transpose=False)
+        packed = _lib.pack_weights_decomposed(wf, cp, rt, num_rel, din, dout, transpose=False)
         ldo = _round4(dout)
         if dctx is None and plans.ep_fwd is not None:
             # edge-parallel path (eplan.py): relation-major dense units -> weighted products per slot -> per-destination sums
@@ -213,15 +217,18 @@ class _RGCNLayerFn(torch.autograd.Function):
         # into its dX store (grad_premasked) needs nothing
         need_a = act == _lib.ACT_SIGMOID or (act == _lib.ACT_RELU and not grad_premasked)
         ctx.need_a = need_a
-        ctx.save_for_backward(xp, wf, rt, out if need_a else None)
+        ctx.save_for_backward(xp, wf, cp, rt, out if need_a else None)
         return out if ldo == dout else out[:, :dout]
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        xp, wf, rt, a_out = ctx.saved_tensors
+        xp, wf, cp, rt, a_out = ctx.saved_tensors
         plans, dctx, flags = ctx.plans, ctx.dctx, ctx.flags
         n, din, dout, num_rel = ctx.dims
-        need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
+        need_x, need_wparam, need_comp, need_root, need_bias = ctx.needs_input_grad[:5]
+        decomposed = cp is not None or wf.dim() == 4
+        need_comp = need_comp and cp is not None
+        need_w = need_wparam or need_comp              # the dense d_W[R, in, out] (for a decomposition: scratch)
         gp = _rows16(g, dout)
         if ctx.need_a:
             gp = _lib.act_backward(a_out, gp, ctx.act)       # dL/dz = dL/da * act'(a)
@@ -259,7 +266,7 @@ class _RGCNLayerFn(torch.autograd.Function):
                 else:
                     _lib.bwd_dw_root(xp, din, gp, dout, pr, pb)
         if need_x:
-            packed_t = _lib.pack_weights(wf, rt, transpose=True)
+            packed_t = _lib.pack_weights_decomposed(wf, cp, rt, num_rel, din, dout, transpose=True)
             ldx = _round4(din)
             mask = xp if ctx.input_relu else None            # x = relu(z_prev): store dL/dz_prev = dx * (x > 0)
             if dctx is None and plans.ep_bwd is not None:
@@ -310,19 +317,31 @@ class _RGCNLayerFn(torch.autograd.Function):
                 dctx.stats["all_reduce"] += 1
                 dctx.stats["all_reduce_bytes"] += acc.numel() * 4
             dw, droot, dbias = views(acc)
-        return dx, dw, droot, dbias, None, None, None, None, None, None
+        dcomp = None
+        if decomposed and dw is not None:
+            dw, dcomp = _lib.decomposed_weight_grads(dw.contiguous(), wf, cp, need_wparam, need_comp)
+        return dx, dw, dcomp, droot, dbias, None, None, None, None, None, None, None, None
 
 
-def rgcn_conv_function(x: Tensor, w_full: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
+def rgcn_conv_function(x: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
                        plans: GraphPlans, dctx: Optional[DistContext] = None, activation: Optional[str] = None,
-                       input_relu: bool = False, grad_premasked: bool = False, flags: int = 0) -> Tensor:
+                       input_relu: bool = False, grad_premasked: bool = False, flags: int = 0,
+                       comp: Optional[Tensor] = None, num_relations: Optional[int] = None, out_channels: Optional[int] = None) -> Tensor:
+    """weight: dense [R, in, out]; or, with ``comp [R, B]``, the bases [B, in, out]; or blocks [R, nb, in / nb, out / nb]
+    (then ``out_channels`` = nb * weight.shape[3])."""
     if x.device.type != "cuda":
         raise RuntimeError("RGCNConv runs only on an MI355X (ROCm 'cuda' device); there is no CPU fallback")
     if activation not in _ACT_CODES:
         raise ValueError(f"fused activation must be one of {list(_ACT_CODES)}")
     _lib.load()
-    return _RGCNLayerFn.apply(x, w_full, root, bias, plans, dctx, _ACT_CODES[activation], bool(input_relu),
-                              bool(grad_premasked), int(flags))
+    if comp is not None:
+        num_rel, dout = int(comp.shape[0]), int(weight.shape[2])
+    elif weight.dim() == 4:
+        num_rel, dout = int(weight.shape[0]), int(weight.shape[1] * weight.shape[3])
+    else:
+        num_rel, dout = int(weight.shape[0]), int(weight.shape[2])
+    return _RGCNLayerFn.apply(x, weight, comp, root, bias, plans, dctx, _ACT_CODES[activation], bool(input_relu),
+                              bool(grad_premasked), int(flags), num_relations or num_rel, out_channels or dout)
 
 
 def glorot_(t: Tensor) -> Tensor:
@@ -411,9 +430,10 @@ class RGCNConv(nn.Module):
                 self.bias.zero_()
 
     def effective_weight(self) -> Tensor:
-        """Dense ``[R, in, out]`` relation weights (differentiable torch ops; O(R*in*out), tiny next to
-        the edge work).  Basis: ``(comp @ weight.view(B,-1)).view(R,in,out)``; block-diagonal: blocks
-        placed on the diagonal of a zero matrix."""
+        """Dense ``[R, in, out]`` relation weights by differentiable torch ops -- NOT on the forward path (the library composes
+        a decomposition inside its weight packer: rgcn_pack_weights_basis / _block); kept as the reference the tests compare
+        that packer with.  Basis: ``(comp @ weight.view(B,-1)).view(R,in,out)``; block-diagonal: blocks placed on the diagonal
+        of a zero matrix."""
         if self.num_bases is not None:
             return (self.comp @ self.weight.view(self.num_bases, -1)).view(
                 self.num_relations, self.in_channels, self.out_channels)
@@ -480,8 +500,9 @@ class RGCNConv(nn.Module):
         first = (plans.fwd if plans.fwd is not None else plans.bwd) if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
         if first is not None and self._use_split_producers(first.chunk):
             flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles; the library falls back where it does not fit
-        return rgcn_conv_function(x, self.effective_weight(), self.root, self.bias, plans, self.dist,
-                                  _activation, _input_relu, _grad_premasked and _activation == "relu", flags)
+        return rgcn_conv_function(x, self.weight, self.root, self.bias, plans, self.dist,
+                                  _activation, _input_relu, _grad_premasked and _activation == "relu", flags,
+                                  comp=self.comp, num_relations=self.num_relations, out_channels=self.out_channels)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}({self.in_channels}, {self.out_channels}, "

@@ -11,11 +11,36 @@ namespace rgcn {
 // which is exactly the (a, b) pairing the consumers use for v_mfma_f32_16x16x4_f32:
 // lane l supplies A[row = l&15][k' = l>>4] and B[k' = l>>4][col = l&15]; MFMA step (j,t) stands for
 // k = 16j + 4k' + t on both operands.
-__global__ void rgcn_pack_kernel(const float* __restrict__ weight, const float* __restrict__ root, int num_rel,
-                                 int din, int dout, int transpose, int KP, int NP, float* __restrict__ packed) {
+// Where the relation weights come from (reference BASELINE.json configs[2]: basis decomposition B = 30):
+//   dense  weight[R', in, out];
+//   basis  W_r = sum_b comp[r, b] * bases[b]   (PyG: (comp @ weight.view(B, -1)).view(R', in, out)), summed b = 0 .. B - 1 in fp32;
+//   block  W_r = blockdiag(blocks[r, 0 .. nb - 1])   with blocks [R', nb, in / nb, out / nb]: zeros off the diagonal.
+// The packers read W_r[k][col] through this, so a decomposed layer never materialises [R', in, out].
+struct WeightSource {
+    const float* weight;    // dense weights, bases, or blocks
+    const float* comp;      // basis: [R', B]
+    const float* root;      // [in, out] or NULL (zeros)
+    int mode;               // 0 dense, 1 basis, 2 block
+    int num_rel, nb, din, dout;      // nb: number of bases / blocks
+    __device__ __forceinline__ float at(int rel, int k, int col) const {      // W_rel[k][col]; rel == num_rel: root
+        if (rel >= num_rel) return root != nullptr ? root[(size_t)k * dout + col] : 0.f;
+        if (mode == 0) return weight[((size_t)rel * din + k) * dout + col];
+        if (mode == 1) {
+            float v = 0.f;
+            for (int b = 0; b < nb; ++b) v = fmaf(comp[(size_t)rel * nb + b], weight[((size_t)b * din + k) * dout + col], v);
+            return v;
+        }
+        const int bi = din / nb, bo = dout / nb, blk = k / bi;
+        if (col / bo != blk) return 0.f;
+        return weight[(((size_t)rel * nb + blk) * bi + (k - blk * bi)) * bo + (col - blk * bo)];
+    }
+};
+
+__global__ void rgcn_pack_kernel(const WeightSource src, int transpose, int KP, int NP, float* __restrict__ packed) {
     const int per_rel = KP * NP;
-    const long total = (long)(num_rel + 1) * per_rel;
-    const int KT = KP / 16, NT = NP / 16;
+    const long total = (long)(src.num_rel + 1) * per_rel;
+    const int KT = KP / 16;
+    const int din = src.din, dout = src.dout;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int rel = (int)(idx / per_rel);
         int rem = (int)(idx % per_rel);
@@ -24,17 +49,13 @@ __global__ void rgcn_pack_kernel(const float* __restrict__ weight, const float* 
         rem >>= 8;
         const int j = rem % KT;
         const int s = rem / KT;
-        (void)NT;
         const int k = 16 * j + 4 * (lane >> 4) + t;
         const int col = 16 * s + (lane & 15);
-        const float* m = rel < num_rel ? weight + (size_t)rel * din * dout : root;
         float v = 0.f;
-        if (m != nullptr) {
-            if (!transpose) {
-                if (k < din && col < dout) v = m[(size_t)k * dout + col];
-            } else {
-                if (k < dout && col < din) v = m[(size_t)col * dout + k];
-            }
+        if (!transpose) {
+            if (k < din && col < dout) v = src.at(rel, k, col);
+        } else {
+            if (k < dout && col < din) v = src.at(rel, col, k);
         }
         packed[idx] = v;
     }
@@ -57,9 +78,9 @@ __device__ __forceinline__ unsigned bf16_rne(float v) {
     const unsigned u = __float_as_uint(v);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-__global__ void rgcn_pack3_kernel(const float* __restrict__ weight, const float* __restrict__ root, int num_rel, int din,
-                                  int dout, int transpose, uint4* __restrict__ packed) {
-    const long total = (long)(num_rel + 1) * kPack3FragsPerRel * 64;
+__global__ void rgcn_pack3_kernel(const WeightSource src, int transpose, uint4* __restrict__ packed) {
+    const long total = (long)(src.num_rel + 1) * kPack3FragsPerRel * 64;
+    const int din = src.din, dout = src.dout;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long rem = idx;
         const int lane = (int)(rem & 63); rem >>= 6;
@@ -68,18 +89,15 @@ __global__ void rgcn_pack3_kernel(const float* __restrict__ weight, const float*
         const int pl = (int)(rem % 3); rem /= 3;
         const int c = (int)(rem & 1); rem >>= 1;
         const int rel = (int)rem;
-        const float* m = rel < num_rel ? weight + (size_t)rel * din * dout : root;
         unsigned h[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 32 * s + 8 * (lane >> 4) + j, col = 32 * c + 16 * ct + (lane & 15);
             float v = 0.f;
-            if (m != nullptr) {
-                if (!transpose) {
-                    if (k < din && col < dout) v = m[(size_t)k * dout + col];
-                } else {
-                    if (k < dout && col < din) v = m[(size_t)col * dout + k];
-                }
+            if (!transpose) {
+                if (k < din && col < dout) v = src.at(rel, k, col);
+            } else {
+                if (k < dout && col < din) v = src.at(rel, col, k);
             }
             unsigned b = bf16_rne(v);
             for (int q = 0; q < pl; ++q) {
@@ -104,6 +122,59 @@ __global__ void rgcn_act_backward_kernel(const float* __restrict__ av, const flo
         for (int c = 0; c < 4; ++c) g[c] = act == RGCN_ACT_RELU ? (y[c] > 0.f ? g[c] : 0.f) : g[c] * y[c] * (1.f - y[c]);
         ((f32x4*)dz)[i] = g;
     }
+}
+
+// ---- gradients of a decomposed layer's parameters from the dense d_W[R', in, out] the weight-gradient kernels produce --------
+// basis: d_bases[b] = sum_r comp[r, b] d_W[r] (r ascending), d_comp[r, b] = <d_W[r], bases[b]> (fixed tree): Appendix A
+__global__ void rgcn_basis_dbases_kernel(const float* __restrict__ dw, const float* __restrict__ comp, int R, int B, int per,
+                                         float* __restrict__ d_bases) {
+    const long total = (long)B * per;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / per), i = (int)(idx % per);
+        float v = 0.f;
+        for (int r = 0; r < R; ++r) v = fmaf(comp[(size_t)r * B + b], dw[(size_t)r * per + i], v);
+        d_bases[idx] = v;
+    }
+}
+// one wave per (r, b): lane-strided partial sums, then a fixed shuffle tree
+__global__ void rgcn_basis_dcomp_kernel(const float* __restrict__ dw, const float* __restrict__ bases, int R, int B, int per,
+                                        float* __restrict__ d_comp) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= (long)R * B) return;
+    const int r = (int)(wave / B), b = (int)(wave % B);
+    float v = 0.f;
+    for (int i = lane; i < per; i += 64) v = fmaf(dw[(size_t)r * per + i], bases[(size_t)b * per + i], v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) d_comp[wave] = v;
+}
+__global__ void rgcn_block_dblocks_kernel(const float* __restrict__ dw, int R, int nb, int din, int dout, float* __restrict__ d_blocks) {
+    const int bi = din / nb, bo = dout / nb;
+    const long total = (long)R * nb * bi * bo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long rem = idx;
+        const int o = (int)(rem % bo); rem /= bo;
+        const int i = (int)(rem % bi); rem /= bi;
+        const int blk = (int)(rem % nb);
+        const int r = (int)(rem / nb);
+        d_blocks[idx] = dw[((size_t)r * din + blk * bi + i) * dout + blk * bo + o];
+    }
+}
+
+static int pack_from(const WeightSource& src, int transpose, float* packed, void* stream) {
+    const int kin = transpose ? src.dout : src.din, nout = transpose ? src.din : src.dout;
+    const int KP = padded_width(kin), NP = padded_width(nout);
+    if (KP == 0 || NP == 0) return RGCN_ERR_WIDTH;
+    const long total = (long)(src.num_rel + 1) * KP * NP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rgcn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, transpose, KP, NP, packed);
+    if (KP == 64 && NP == 64) {      // 64 x 64 layers also carry the bf16 x 3 planes (rgcn_tile3p_kernel), behind the fp32 fragments
+        const long lanes = (long)(src.num_rel + 1) * kPack3FragsPerRel * 64;
+        hipLaunchKernelGGL(rgcn_pack3_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, transpose,
+                           (uint4*)(packed + total));
+    }
+    return (int)hipGetLastError();
 }
 
 }  // namespace rgcn
@@ -147,18 +218,48 @@ extern "C" int rgcn_pack_weights(const float* weight, const float* root, int num
                                  int transpose, float* packed, void* stream) {
     if (!weight || !packed) return RGCN_ERR_NULL;
     if (num_relations <= 0) return RGCN_ERR_PLAN;
-    const int kin = transpose ? dout : din, nout = transpose ? din : dout;
-    const int KP = padded_width(kin), NP = padded_width(nout);
-    if (KP == 0 || NP == 0) return RGCN_ERR_WIDTH;
-    const long total = (long)(num_relations + 1) * KP * NP;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(rgcn_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, root, num_relations,
-                       din, dout, transpose, KP, NP, packed);
-    if (pack3_floats(num_relations, KP, NP) != 0) {
-        const long lanes = (long)(num_relations + 1) * kPack3FragsPerRel * 64;
-        hipLaunchKernelGGL(rgcn_pack3_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, root,
-                           num_relations, din, dout, transpose, (uint4*)(packed + total));
+    return pack_from(WeightSource{weight, nullptr, root, 0, num_relations, 0, din, dout}, transpose, packed, stream);
+}
+
+extern "C" int rgcn_pack_weights_basis(const float* bases, const float* comp, const float* root, int num_relations, int num_bases,
+                                       int din, int dout, int transpose, float* packed, void* stream) {
+    if (!bases || !comp || !packed) return RGCN_ERR_NULL;
+    if (num_relations <= 0 || num_bases <= 0) return RGCN_ERR_PLAN;
+    return pack_from(WeightSource{bases, comp, root, 1, num_relations, num_bases, din, dout}, transpose, packed, stream);
+}
+
+extern "C" int rgcn_pack_weights_block(const float* blocks, const float* root, int num_relations, int num_blocks, int din, int dout,
+                                       int transpose, float* packed, void* stream) {
+    if (!blocks || !packed) return RGCN_ERR_NULL;
+    if (num_relations <= 0 || num_blocks <= 0 || din % num_blocks != 0 || dout % num_blocks != 0) return RGCN_ERR_PLAN;
+    return pack_from(WeightSource{blocks, nullptr, root, 2, num_relations, num_blocks, din, dout}, transpose, packed, stream);
+}
+
+extern "C" int rgcn_basis_backward(const float* d_w, const float* bases, const float* comp, int num_relations, int num_bases, int din,
+                                   int dout, float* d_bases, float* d_comp, void* stream) {
+    if (!d_w || !bases || !comp) return RGCN_ERR_NULL;
+    if (num_relations <= 0 || num_bases <= 0 || din <= 0 || dout <= 0) return RGCN_ERR_PLAN;
+    const int per = din * dout;
+    hipStream_t s = (hipStream_t)stream;
+    if (d_bases != nullptr) {
+        const long total = (long)num_bases * per;
+        hipLaunchKernelGGL(rgcn_basis_dbases_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_w, comp, num_relations,
+                           num_bases, per, d_bases);
     }
+    if (d_comp != nullptr) {
+        const long waves = (long)num_relations * num_bases;
+        hipLaunchKernelGGL(rgcn_basis_dcomp_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, d_w, bases, num_relations,
+                           num_bases, per, d_comp);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int rgcn_block_backward(const float* d_w, int num_relations, int num_blocks, int din, int dout, float* d_blocks, void* stream) {
+    if (!d_w || !d_blocks) return RGCN_ERR_NULL;
+    if (num_relations <= 0 || num_blocks <= 0 || din % num_blocks != 0 || dout % num_blocks != 0) return RGCN_ERR_PLAN;
+    const long total = (long)num_relations * din * dout / num_blocks;
+    hipLaunchKernelGGL(rgcn_block_dblocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_w,
+                       num_relations, num_blocks, din, dout, d_blocks);
     return (int)hipGetLastError();
 }
 

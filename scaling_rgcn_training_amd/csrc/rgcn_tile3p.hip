@@ -54,6 +54,13 @@ __device__ __forceinline__ unsigned long long p3_stamp() {
 #ifndef RGCN_P3_TRUNC
 #define RGCN_P3_TRUNC 0
 #endif
+// 1: the consumers drain their LDS queue (s_waitcnt lgkmcnt(0)) in front of EVERY chunk barrier; 0: only where a tile closes.
+// Per-wave stamps (round 3, profiles/r03a_*) show every consumer wave waiting ~400 cycles per chunk at that barrier with the
+// producers long there -- the drain of its last accumulator stores; without it the same wait moves to the next chunk's first
+// lgkmcnt(0) (scalar metadata): 9.39 / 9.33 ms with, 9.42 / 9.32 without, A/B on one box.  Kept at 1.
+#ifndef RGCN_P3_DRAIN
+#define RGCN_P3_DRAIN 1
+#endif
 
 constexpr int kP3Threads = 512;                          // 4 producer + 4 consumer waves
 constexpr int kP3CH = 128;                               // rows of a ring slot == plan chunk
@@ -265,8 +272,8 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     }
     wait_vmcnt<0>();
 #ifdef RGCN_P3_STAMPS
-    if (g_p3_stamps && pw == 0 && lane == 0) {
-        unsigned long long* o = g_p3_stamps + (size_t)blockIdx.x * 16;
+    if (g_p3_stamps && lane == 0) {      // every wave: [workgroup][wave 0..11][wait, issue / compute, split / swap, barrier, chunks]
+        unsigned long long* o = g_p3_stamps + ((size_t)blockIdx.x * 12 + pw) * 8;
         o[0] = sp_wait; o[1] = sp_issue; o[2] = sp_split; o[3] = sp_bar; o[4] = nch;
     }
 #endif
@@ -567,7 +574,12 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
             pending = it + 2 < nch && rel_next2 != rel_next;
             if (pending) prefetch_rel(rel_next2);
             P3S(t3s);
-            wg_barrier();
+            // The barrier that hands the ring slot back.  What it must order is this wave's READS of the slot -- all consumed by
+            // MFMAs by now -- not its accumulator stores: those rows are read again only by this wave (LDS operations of a wave
+            // execute in order) until the tile closes.  So no lgkmcnt(0) in front of it except where a tile closes and the other
+            // consumer waves read these columns (RGCN_P3_DRAIN=1: always drain, the round-2 behaviour)
+            if (RGCN_P3_DRAIN || (it + 1 == tend) || it + 1 == nch) wg_barrier();
+            else asm volatile("s_barrier" ::: "memory");
             if (it + 1 == tend && it + 1 < nch) {
                 // this chunk closed a tile: the consumer threads store it and reset the accumulator; the producers wait at
                 // the same extra barrier with the next tile's first chunks already in LDS / in flight
@@ -581,9 +593,9 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
             P3A(sc_meta, t0s, t1s); P3A(sc_comp, t1s, t2s); P3A(sc_swap, t2s, t3s); P3A(sc_bar, t3s, t4s);
         }
 #ifdef RGCN_P3_STAMPS
-        if (g_p3_stamps && (cw == 0 || cw == kConsumers - 1) && lane == 0) {       // first wave of team A, last wave of team B
-            unsigned long long* o = g_p3_stamps + (size_t)blockIdx.x * 16 + (cw == 0 ? 8 : 12);
-            o[0] = sc_meta; o[1] = sc_comp; o[2] = sc_swap; o[3] = sc_bar;
+        if (g_p3_stamps && lane == 0) {
+            unsigned long long* o = g_p3_stamps + ((size_t)blockIdx.x * 12 + 4 + cw) * 8;
+            o[0] = sc_meta; o[1] = sc_comp; o[2] = sc_swap; o[3] = sc_bar; o[4] = nch;
         }
 #endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the consumers is pending when the producer code follows

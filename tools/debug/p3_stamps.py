@@ -10,7 +10,7 @@ os.makedirs(os.path.dirname(so), exist_ok=True)
 H = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 DEFS = os.environ.get("P3_DEFS", "").split()
 subprocess.run(H + ["-DRGCN_P3_STAMPS"] + DEFS + ["-c", os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_tile3p.hip"), "-o", so + ".o"], check=True)
-subprocess.run(H + ["-shared"] + [os.path.join(B, f"rgcn_{n}.o") for n in ("tile_fp32", "dw_relmajor", "dw_tile", "dw_root", "abi", "plan")] + [so + ".o", "-o", so], check=True)
+subprocess.run(H + ["-shared"] + [os.path.join(B, f"rgcn_{n}.o") for n in ("tile_fp32", "dw_relmajor", "dw_tile", "dw_root", "ep", "abi", "plan")] + [so + ".o", "-o", so], check=True)
 from scaling_rgcn_training_amd import _lib
 _lib.LIB_PATH = so
 lib = _lib.load()
@@ -24,7 +24,7 @@ if os.environ.get("VT_UNIQ") == "1":
     ei = torch.stack([ei[0], key // 32]); et = key % 32
 plans = P.build_graph_plans_device(ei, et, n, 32, 224, chunk=128, dw_tiles=False, split=os.environ.get("VT_SPLIT", "0") == "1")
 fp = plans.fwd
-stamps = torch.zeros(fp.n_tiles * 16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(fp.n_tiles * 12 * 8, dtype=torch.int64, device=dev)
 lib.rgcn_debug_set_p3_stamps.argtypes = [ctypes.c_void_p]
 assert lib.rgcn_debug_set_p3_stamps(stamps.data_ptr()) == 0
 out = torch.empty(n, 64, device=dev)
@@ -33,11 +33,13 @@ for _ in range(2):
     stamps.zero_()
     _lib.fwd(_lib.plan_struct(fp), x, 64, pk, None, out, 64, 0, _lib.FLAG_SPLIT_PRODUCERS)
 torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64)
-nch = s[:, 4].sum()
+s = stamps.cpu().numpy().reshape(-1, 12, 8).astype(np.float64)
+nch = s[:, 0, 4].sum()
 print("defs", DEFS, "layout", fp.layout, "tiles", fp.n_tiles, "chunks", int(nch))
-for i, nm in ((0, "prod wait batch"), (1, "prod issue batch"), (2, "prod split + store"), (3, "prod barrier"),
-              (8, "cons metadata"), (9, "cons compute"), (10, "cons W swap + prefetch"), (11, "cons barrier"),
-              (12, "consB metadata"), (13, "consB compute"), (14, "consB W swap + prefetch"), (15, "consB barrier")):
-    print(f"{nm:24s} {s[:, i].sum() / nch:9.1f} cycles/chunk")
-print("producer total %.1f  consumer total %.1f" % (s[:, 0:4].sum() / nch, s[:, 8:12].sum() / nch))
+print("cycles per chunk, every wave of the workgroup (producers: wait batch / issue batch / split + store / barrier; consumers: metadata / compute / W swap / barrier)")
+for wv in range(12):
+    if s[:, wv, 4].sum() == 0:
+        continue
+    role = "producer %d" % wv if wv < 4 else "consumer %d" % (wv - 4)
+    v = s[:, wv, :4].sum(0) / nch
+    print(f"{role:12s} {v[0]:8.1f} {v[1]:8.1f} {v[2]:8.1f} {v[3]:8.1f}   total {v.sum():8.1f}")
