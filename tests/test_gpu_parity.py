@@ -374,9 +374,6 @@ def test_fused_activation_standalone_relu_backward(dev):
         assert torch.equal(a, b)
 
 
-    assert np.array_equal(res3[2], res1[2])          # dW does not depend on the forward kernel
-
-
 @pytest.mark.parametrize("split", [False, True], ids=["fp32", "bf16x3"])
 @pytest.mark.parametrize("n,e,r,skew", [(5000, 90000, 7, False), (20000, 600000, 32, False), (3000, 200000, 3, True), (700, 5000, 32, False)])
 def test_dw_tile_major_kernel(dev, n, e, r, skew, split):
