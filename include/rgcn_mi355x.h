@@ -262,6 +262,15 @@ typedef struct rgcn_edge_units {
     const float* slot_w;       /* [n_units * 64] edge weight, 0 = padding */
 } rgcn_edge_units_t;
 
+/* The unit arrays come from the plan builder itself: rgcn_plan_build_begin / _finish with layout = 2, chunk = 64 (tile is
+ * ignored) lay the owned range out as ONE tile, i.e. relation-major: chunk_rel / chunk_cnt are unit_rel / unit_cnt, slot_src /
+ * slot_w the slots, slot_row the destination row of every slot (n_owned = padding), rel_order = 0 .. n_units - 1 -- the same
+ * rgcn_plan_t is what rgcn_bwd_dw walks.  rgcn_eplan_segments then sorts the slots by destination: seg_idx [n_slots] (its first
+ * seg_ptr[n_owned] entries are the real slots ordered by (destination row, slot)), seg_ptr [n_owned + 1].  Workspace:
+ * rgcn_plan_workspace_bytes(n_slots, 0, 1, 16).  Destinations with more than a few hundred rows are summed in levels: cut
+ * [seg_ptr[i], seg_ptr[i + 1]) into pieces of at most P rows (scaling_rgcn_training_amd/eplan.py segment_levels, P = 256). */
+int rgcn_eplan_segments(const int32_t* slot_row, int64_t n_slots, int32_t n_owned, void* workspace, size_t workspace_bytes,
+                        int32_t* seg_ptr, int32_t* seg_idx, void* stream);
 /* z: [n_units * 64, ldz] (rows of unused row tiles are left untouched); packed_w: rgcn_pack_weights(..., transpose) */
 int rgcn_ep_transform(const rgcn_edge_units_t* units, const float* x, int ldx, int din, const float* packed_w, float* z,
                       int ldz, int dout, unsigned flags, void* stream);

@@ -22,7 +22,7 @@ EXPORTS = (
     "rgcn_plan_workspace_bytes", "rgcn_edge_weights", "rgcn_plan_build_begin", "rgcn_plan_build_finish",
     "rgcn_dw_tiles_geometry", "rgcn_dw_tiles_walk", "rgcn_bwd_dw_tiles_workspace_bytes", "rgcn_bwd_dw_tiles",
     "rgcn_bwd_dw_root_workspace_bytes", "rgcn_bwd_dw_root", "rgcn_ep_transform", "rgcn_ep_segment_sum",
-    "rgcn_pack_weights_basis", "rgcn_pack_weights_block", "rgcn_basis_backward", "rgcn_block_backward",
+    "rgcn_pack_weights_basis", "rgcn_pack_weights_block", "rgcn_basis_backward", "rgcn_block_backward", "rgcn_eplan_segments",
 )
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
@@ -131,6 +131,8 @@ def load() -> C.CDLL:
     lib.rgcn_basis_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.rgcn_block_backward.restype = i32
     lib.rgcn_block_backward.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.rgcn_eplan_segments.restype = i32
+    lib.rgcn_eplan_segments.argtypes = [vp, i64, i32, vp, sz, vp, vp, vp]
     lib.rgcn_ep_transform.restype = i32
     lib.rgcn_ep_transform.argtypes = [C.POINTER(RgcnEdgeUnits), vp, i32, i32, vp, vp, i32, i32, u32, vp]
     lib.rgcn_ep_segment_sum.restype = i32
@@ -313,13 +315,14 @@ def edge_weights(graph: RgcnGraphStruct, aggr: str, ws: torch.Tensor) -> torch.T
 
 
 def plan_build(graph: RgcnGraphStruct, w: torch.Tensor, transposed: bool, node_begin: int, node_end: int, tile: int,
-               chunk: int, ws: torch.Tensor, split: bool = False):
-    """-> (RgcnPlanStruct, dict of the ten device arrays, n_edges placed)"""
+               chunk: int, ws: torch.Tensor, split=False):
+    """-> (RgcnPlanStruct, dict of the ten device arrays, n_edges placed).  split: plan layout (False / True = 0 / 1; 2 =
+    relation-major units of the edge-parallel path)"""
     lib, dev = load(), ws.device
     sizes = RgcnPlanSizes()
     with torch.cuda.device(dev):
         check(lib.rgcn_plan_build_begin(C.byref(graph), w.data_ptr() if graph.num_edges else None, int(transposed),
-                                        int(node_begin), int(node_end), int(tile), int(chunk), int(bool(split)), ws.data_ptr(),
+                                        int(node_begin), int(node_end), int(tile), int(chunk), int(split), ws.data_ptr(),
                                         ws.numel(), C.byref(sizes), _stream(ws)), "rgcn_plan_build_begin")
         i32 = dict(dtype=torch.int32, device=dev)
         arr = {
@@ -406,3 +409,17 @@ def ep_layer(ep, x: torch.Tensor, din: int, packed: torch.Tensor, bias: Optional
                                           _ptr(mask) if final else None, mask.stride(0) if (final and mask is not None) else 0,
                                           int(final), dst.data_ptr(), dst.stride(0), st), "rgcn_ep_segment_sum")
             cur = dst
+
+
+def eplan_segments(slot_row: torch.Tensor, n_owned: int):
+    """(seg_ptr int32 [n_owned + 1], seg_idx int32 [real slots]) of a relation-major plan's slots (rgcn_eplan_segments)"""
+    lib = load()
+    n_slots = int(slot_row.numel())
+    dev = slot_row.device
+    seg_ptr = torch.empty(n_owned + 1, dtype=torch.int32, device=dev)
+    seg_idx = torch.empty(max(n_slots, 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = torch.empty(lib.rgcn_plan_workspace_bytes(n_slots, 0, 1, 16), dtype=torch.uint8, device=dev)
+        check(lib.rgcn_eplan_segments(slot_row.data_ptr(), n_slots, int(n_owned), ws.data_ptr(), ws.numel(), seg_ptr.data_ptr(),
+                                      seg_idx.data_ptr(), _stream(slot_row)), "rgcn_eplan_segments")
+    return seg_ptr, seg_idx

@@ -688,8 +688,14 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     int st = check_graph(g);
     if (st != RGCN_OK) return st;
     if (!sizes || !workspace || (g->num_edges > 0 && !w)) return RGCN_ERR_NULL;
-    if (tile <= 0 || (tile % 16) != 0 || tile > 32768 || (chunk != 64 && chunk != 128)) return RGCN_ERR_PLAN;
-    if (layout != 0 && !(layout == 1 && chunk == 128)) return RGCN_ERR_PLAN;
+    if (layout == 2) {
+        // relation-major units (the edge-parallel path, rgcn_ep_*): ONE tile that spans the owned range makes the key order
+        // (tile, relation, row, gathered node) relation-major; the rows of a relation are dealt over its row tiles as in layout 0
+        if (chunk != 64 || node_end - node_begin > (1 << 24)) return RGCN_ERR_PLAN;
+        tile = ((node_end - node_begin + 15) / 16) * 16;
+    }
+    if (tile <= 0 || (tile % 16) != 0 || (tile > 32768 && layout != 2) || (chunk != 64 && chunk != 128)) return RGCN_ERR_PLAN;
+    if (layout != 0 && layout != 2 && !(layout == 1 && chunk == 128)) return RGCN_ERR_PLAN;
     // (node_begin need not be a tile multiple: tiles count from node_begin.  Callers that want a rank's tiles to BE the
     // single-rank tiles -- bit-identical outputs -- align their ranges themselves: scaling_rgcn_training_amd/dist.py)
     if (node_begin < 0 || node_end <= node_begin || node_end > g->num_nodes) return RGCN_ERR_PLAN;
@@ -749,7 +755,8 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     if ((st = read_u32(ws.sb.sums + scan_blocks(n_groups), &n_chunks, s)) != 0) return st;
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     memset(sizes, 0, sizeof(*sizes));
-    sizes->n_tiles = (int32_t)n_tiles;
+    // (layout 2: the plan struct reports tiles of at most 32,768 nodes -- nothing walks them, the kernels' argument checks do)
+    sizes->n_tiles = layout == 2 ? (int32_t)((n_own + 32767u) / 32768u) : (int32_t)n_tiles;
     sizes->n_chunks = (int32_t)n_chunks;
     sizes->n_units = (int32_t)n_units;
     sizes->n_slots = (int64_t)n_chunks * chunk;
@@ -789,13 +796,16 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     u32* dstl = (u32*)slot_row;   // scratch inside the output array until row_tile_kernel (see fill_slots_kernel)
     hipLaunchKernelGGL(fill_slots_kernel, dim3(grid_for(n_slots)), dim3(256), 0, s, n_slots, bs.n_nodes, bs.tile, slot_src, slot_w, dstl);
     u32* split = ws.scan_a;       // cut position of every chunk (layout 1); n_chunks <= nmax
+    const u32 placement = bs.layout == 2 ? 0u : bs.layout;        // relation-major units: layout 0's dealing inside the one tile
     hipLaunchKernelGGL(chunk_meta_kernel, dim3(grid_for(bs.n_chunks)), dim3(256), 0, s, ws.gch, ws.gstart, ws.gkey, bs.n_groups,
-                       bs.n_chunks, bs.chunk, bs.layout, ws.sb.k[bs.ubuf], bs.kl, split, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
+                       bs.n_chunks, bs.chunk, placement, ws.sb.k[bs.ubuf], bs.kl, split, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
     hipLaunchKernelGGL(place_kernel, dim3(grid_for(bs.n_unique)), dim3(256), 0, s, ws.sb.k[bs.ubuf], ws.sb.v[bs.ubuf], bs.n_unique,
-                       ws.scan_b, ws.gstart, ws.gch, bs.chunk, bs.layout, split, bs.kl, slot_src, slot_w, dstl);
+                       ws.scan_b, ws.gstart, ws.gch, bs.chunk, placement, split, bs.kl, slot_src, slot_w, dstl);
     hipLaunchKernelGGL(row_tile_kernel, dim3(grid_for(n_rt)), dim3(256), 0, s, dstl, n_rt, bs.chunk, bs.tile, bs.n_own, chunk_tile,
                        slot_acc, slot_row, chunk_flags);
-    const u32 n_tiles = (bs.n_own + bs.tile - 1) / bs.tile;
+    const u32 struct_tile = bs.layout == 2 ? (bs.tile < 32768u ? bs.tile : 32768u) : bs.tile;
+    const u32 n_tiles = (bs.n_own + struct_tile - 1) / struct_tile;
+    // (layout 2: chunk_tile is 0 throughout, so tile_ptr comes out as [0, n_chunks, n_chunks, ...]: never walked)
     hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for((u64)n_tiles + 1)), dim3(256), 0, s, chunk_tile, bs.n_chunks, n_tiles,
                        (int32_t*)plan->tile_ptr);
     // ---- the weight-gradient walk: chunks stably re-sorted by relation, cut into 64-slot units ---------------------
@@ -811,11 +821,50 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     plan->n_nodes = (int32_t)bs.n_nodes;
     plan->n_owned = (int32_t)bs.n_own;
     plan->num_relations = (int32_t)bs.num_rel;
-    plan->tile = (int32_t)bs.tile;
+    plan->tile = (int32_t)struct_tile;
     plan->n_tiles = (int32_t)n_tiles;
     plan->n_chunks = (int32_t)bs.n_chunks;
     plan->chunk = (int32_t)bs.chunk;
     plan->n_units = (int32_t)bs.n_units;
     plan->layout = (int32_t)bs.layout;
+    return (int)hipGetLastError();
+}
+
+// ---- destination-major index over the slots of a relation-major plan (layout 2): what rgcn_ep_segment_sum walks -----------------
+// seg_idx = the real slots (slot_row < n_owned) ordered by (destination row, slot index): a stable radix sort of (slot_row, slot);
+// seg_ptr[d] = first position of destination d (lower bound in the sorted rows), seg_ptr[n_owned] = number of real slots.
+__global__ void slot_keys_kernel(const int32_t* __restrict__ slot_row, u32 n_slots, u64* __restrict__ keys, u32* __restrict__ vals) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    keys[i] = (u64)(u32)slot_row[i];
+    vals[i] = i;
+}
+__global__ void seg_ptr_kernel(const u64* __restrict__ keys, u32 n_slots, u32 n_owned, int32_t* __restrict__ seg_ptr) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_owned) return;
+    u32 lo = 0, hi = n_slots;               // first sorted slot whose row is >= d (padding slots carry row n_owned: they sort last)
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if ((u32)keys[mid] < d) lo = mid + 1; else hi = mid;
+    }
+    seg_ptr[d] = (int32_t)lo;
+}
+__global__ void copy_u32_kernel(const u32* __restrict__ in, u32 n, int32_t* __restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+
+extern "C" int rgcn_eplan_segments(const int32_t* slot_row, int64_t n_slots, int32_t n_owned, void* workspace, size_t workspace_bytes,
+                                   int32_t* seg_ptr, int32_t* seg_idx, void* stream) {
+    if (!slot_row || !workspace || !seg_ptr || !seg_idx) return RGCN_ERR_NULL;
+    if (n_slots <= 0 || n_slots >= (int64_t)0xFFFFFFFFll || n_owned <= 0) return RGCN_ERR_PLAN;
+    Workspace ws = carve(workspace, (u64)n_slots, 1);
+    if (workspace_bytes < ws.bytes) return RGCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const u32 n = (u32)n_slots;
+    hipLaunchKernelGGL(slot_keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, slot_row, n, ws.sb.k[0], ws.sb.v[0]);
+    const int cur = radix_sort_pairs(ws.sb, n, bits_for((u64)n_owned), s);
+    hipLaunchKernelGGL(seg_ptr_kernel, dim3(grid_for((u64)n_owned + 1)), dim3(256), 0, s, ws.sb.k[cur], n, (u32)n_owned, seg_ptr);
+    hipLaunchKernelGGL(copy_u32_kernel, dim3(grid_for(n)), dim3(256), 0, s, ws.sb.v[cur], n, seg_idx);
     return (int)hipGetLastError();
 }

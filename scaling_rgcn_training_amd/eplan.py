@@ -23,8 +23,9 @@ The same units are a dense relation-major walk for the weight-gradient kernels (
 nothing but slots and units), where the tile-major plan's units hold a handful of rows each on such graphs.
 
 Cost: Z is written and read once (2 x rows x 4 x out bytes beside the gathers), which is why the headline graph stays on
-the tile kernels (``choose_path``).  The arrays are built with torch sorts (one-time, per graph and direction); unlike
-the tile-major plan there is no device builder behind the C ABI for them yet.
+the tile kernels (``choose_path``).  On the GPU the arrays come from the library's own plan builder (``build_edge_plan_device``:
+rgcn_plan_build_* with layout 2 -- one relation-major "tile" -- and rgcn_eplan_segments); ``build_edge_plan`` is its torch twin
+(bit-identical: tests/test_gpu_ep.py) and what the CPU-only tests walk.
 """
 from __future__ import annotations
 
@@ -155,8 +156,13 @@ def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_n
     ubase = torch.cumsum(runits, 0) - runits
     rstart = torch.cumsum(rcnt, 0) - rcnt
     n_units = int(runits.sum())
-    slot = ubase[r_all] * UNIT + (torch.arange(n_rows, device=dev) - rstart[r_all])
     n_slots = n_units * UNIT
+    # rows of a relation are dealt over its row tiles exactly as the tile-major plan deals a group (plan.build_plan layout 0: row
+    # j -> row tile j mod nt, place j div nt, nt = ceil(rows / 16)): the device builder lays a relation-major plan out as ONE tile
+    # (csrc/rgcn_plan.hip layout 2) and this is its torch twin, bit for bit
+    rnt = (rcnt + 15) // 16
+    j = torch.arange(n_rows, device=dev) - rstart[r_all]
+    slot = ubase[r_all] * UNIT + (j % rnt[r_all]) * 16 + j // rnt[r_all]
     slot_src = torch.full((n_slots,), n_nodes, dtype=torch.int32, device=dev)
     slot_w = torch.zeros(n_slots, dtype=torch.float32, device=dev)
     slot_row = torch.full((n_slots,), n_own, dtype=torch.int32, device=dev)
@@ -165,17 +171,43 @@ def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_n
     slot_row[slot] = loc.to(torch.int32)
     unit_rel = torch.repeat_interleave(torch.arange(r1, device=dev), runits).to(torch.int32)
     uidx = torch.arange(n_units, device=dev) - ubase[unit_rel.long()]
-    used = torch.clamp(rcnt[unit_rel.long()] - uidx * UNIT, max=UNIT)
-    unit_cnt = ((used + 15) // 16 * 16).to(torch.int32)
-    # destination-major index over the slots: stable, so a destination's rows stay in (relation, gathered row) order
-    order = torch.sort(loc, stable=True)[1]
-    seg_idx = slot[order].to(torch.int32)
+    unit_cnt = (torch.clamp(rnt[unit_rel.long()] - uidx * (UNIT // 16), max=UNIT // 16) * 16).to(torch.int32)
+    # destination-major index over the slots, a destination's rows in slot order (= relation-major): rgcn_eplan_segments
+    seg_idx = torch.sort(loc * max(n_slots, 1) + slot)[0] % max(n_slots, 1)
+    seg_idx = seg_idx.to(torch.int32)
     dcnt = torch.bincount(loc, minlength=n_own)
     lv = segment_levels(dcnt, piece)
     levels = [(p.to(torch.int32), seg_idx if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
     return EdgePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, n_units=n_units,
                     n_rows=n_rows, unit_rel=unit_rel, unit_cnt=unit_cnt, slot_src=slot_src, slot_w=slot_w, slot_row=slot_row,
                     levels=levels, max_rows_per_dst=int(dcnt.max()) if n_own else 0)
+
+
+def build_edge_plan_device(graph, w: Tensor, transposed: bool, n_nodes: int, num_relations: int, ws: Tensor,
+                           node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE) -> EdgePlan:
+    """The same plan by the library's own builder (csrc/rgcn_plan.hip): rgcn_plan_build_begin / _finish with layout 2 lay the
+    owned range out as one relation-major "tile", rgcn_eplan_segments sorts the slots by destination; only the sum levels of
+    hubs (arithmetic on seg_ptr) stay here.  graph / w / ws: _lib.graph_struct, _lib.edge_weights, _lib.plan_workspace."""
+    from . import _lib
+    if node_end is None:
+        node_end = n_nodes
+    n_own = node_end - node_begin
+    ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, 16, UNIT, ws, 2)
+    seg_ptr, seg_idx = _lib.eplan_segments(a["slot_row"], n_own)
+    counts = (seg_ptr[1:] - seg_ptr[:-1]).to(torch.int64)
+    n_rows = int(seg_ptr[-1])
+    lv = segment_levels(counts, piece)
+    levels = [(p.to(torch.int32), seg_idx[:n_rows] if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
+    ep = EdgePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, n_units=int(ps.n_chunks),
+                  n_rows=n_rows, unit_rel=a["chunk_rel"], unit_cnt=a["chunk_cnt"], slot_src=a["slot_src"], slot_w=a["slot_w"],
+                  slot_row=a["slot_row"], levels=levels, max_rows_per_dst=int(counts.max()) if n_own else 0)
+    # the same arrays are the relation-major walk of the weight-gradient kernels: the struct the builder filled
+    from .plan import TilePlan
+    tp = TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, tile=int(ps.tile),
+                  chunk=UNIT, n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None, layout=2, **a)
+    tp._cstruct = ps
+    ep._tile_plan = tp
+    return ep
 
 
 # ---- which path: cost model of one forward / dX launch ---------------------------------------------------------------

@@ -495,16 +495,16 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
     out = []
     for (fb, fe), (bb, be) in rs:
         gp = GraphPlans(fwd=None, bwd=None, num_edges=e)
-        if paths[0] == "ep":       # edge-parallel direction: torch sorts on the device (eplan.py), the library's edge weights
-            from .eplan import build_edge_plan
-            gp.ep_fwd = build_edge_plan(edge_index[0], edge_index[1], edge_type, w, n_nodes, num_relations, fb, fe)
+        if paths[0] == "ep":       # edge-parallel direction: relation-major units + destination-major segments (eplan.py)
+            from .eplan import build_edge_plan_device
+            gp.ep_fwd = build_edge_plan_device(graph, w, False, n_nodes, num_relations, ws, fb, fe)
         else:
             gp.fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws, split)
             if ranges is not None:
                 gp.num_edges = gp.fwd.n_edges
         if paths[1] == "ep":
-            from .eplan import build_edge_plan
-            gp.ep_bwd = build_edge_plan(edge_index[1], edge_index[0], edge_type, w, n_nodes, num_relations, bb, be)
+            from .eplan import build_edge_plan_device
+            gp.ep_bwd = build_edge_plan_device(graph, w, True, n_nodes, num_relations, ws, bb, be)
         else:
             gp.bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
         if dw_tiles and paths[0] != "ep" and fe > fb:

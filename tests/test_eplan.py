@@ -31,15 +31,18 @@ def emulate_ep(ep, x, w_all, bias=None):
 
 def _check_units(ep, n_real_rows):
     assert ep.n_rows == n_real_rows
-    valid = ep.slot_src.view(-1, 64) < ep.n_nodes
+    valid = ep.slot_src.view(-1, 16) < ep.n_nodes                                            # per 16-slot row tile
     nvalid = valid.sum(1)
-    assert torch.all(valid == (torch.arange(64)[None, :] < nvalid[:, None]))                  # real slots are a prefix of a unit
-    assert torch.all(ep.unit_cnt == (nvalid + 15) // 16 * 16) and torch.all(nvalid > 0)
+    assert torch.all(valid == (torch.arange(16)[None, :] < nvalid[:, None]))                  # real slots are a prefix of every row tile
+    used = (torch.arange(4)[None, :] * 16 < ep.unit_cnt.long()[:, None]).reshape(-1)
+    assert torch.all(nvalid[used] > 0) and torch.all(nvalid[~used] == 0)                      # unit_cnt = the unit's row tiles
     assert torch.all(ep.unit_rel[1:] >= ep.unit_rel[:-1])                                    # relation-major
-    full = nvalid == 64
-    last_of_rel = torch.cat([ep.unit_rel[1:] != ep.unit_rel[:-1], torch.tensor([True])])
-    assert torch.all(full | last_of_rel), "only the last unit of a relation is padded"
-    assert torch.all(ep.slot_w.view(-1, 64)[~valid] == 0) and torch.all(ep.slot_row.view(-1, 64)[~valid] == ep.n_owned)
+    # a relation's rows are dealt over ceil(rows / 16) row tiles (15 or 16 rows each once it has more than one): dense units
+    rows_rel = torch.zeros(ep.num_relations + 1, dtype=torch.long).index_add_(0, ep.unit_rel.long().repeat_interleave(4), nvalid)
+    tiles_rel = torch.zeros(ep.num_relations + 1, dtype=torch.long).index_add_(0, ep.unit_rel.long().repeat_interleave(4), used.long())
+    assert torch.equal(tiles_rel, (rows_rel + 15) // 16)
+    assert torch.all(ep.slot_w.view(-1, 16)[~valid] == 0) and torch.all(ep.slot_row.view(-1, 16)[~valid] == ep.n_owned)
+    valid = valid.view(-1, 64)
     # level 0 reads every real slot exactly once; every level's output count feeds the next; the last one is the nodes
     ptr0, idx0, _ = ep.levels[0]
     assert sorted(idx0.tolist()) == torch.nonzero(valid.view(-1)).view(-1).tolist()

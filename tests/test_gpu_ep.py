@@ -157,3 +157,36 @@ def test_ep_layer_step_is_hipgraph_capturable(dev):
     torch.cuda.synchronize()
     for a, b in zip(eager, (x.grad, conv.weight.grad, conv.root.grad)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,e,r,skew,rng", [(8243, 49838, 89, False, None), (3000, 40000, 45, True, None), (700, 9000, 3, True, (128, 448)),
+                                            (40, 0, 2, False, None), (100000, 2000000, 7, True, None)])
+def test_device_edge_plan_is_bit_identical_to_the_torch_twin(dev, n, e, r, skew, rng):
+    """The edge plan behind the C ABI -- rgcn_plan_build_begin / _finish with layout 2 (one relation-major 'tile') +
+    rgcn_eplan_segments -- against eplan.build_edge_plan (torch sorts): units, slots, destination-major index, sum levels, and
+    the plan struct the weight-gradient kernels walk; both directions, an owned sub-range, hubs, an edgeless graph."""
+    from scaling_rgcn_training_amd import _lib, eplan as E, plan as P
+    ei, et = O.synthetic_graph(n, max(e, 1), r, seed=n + 1, skew=skew)
+    if e == 0:
+        ei, et = ei[:, :0], et[:0]
+    else:
+        ei[:, 5:25] = ei[:, 30:50]             # duplicate triples
+        et[5:25] = et[30:50]
+    eid, etd = ei.to(dev), et.to(dev)
+    b, en = rng if rng is not None else (0, n)
+    graph, keep = _lib.graph_struct(eid, etd, n, r)
+    ws = _lib.plan_workspace(int(etd.shape[0]), en - b, r, 16, dev)
+    w = _lib.edge_weights(graph, "mean", ws)
+    for transposed in (False, True):
+        got = E.build_edge_plan_device(graph, w, transposed, n, r, ws, b, en)
+        g_, s_ = (eid[1], eid[0]) if transposed else (eid[0], eid[1])
+        want = E.build_edge_plan(g_, s_, etd, w, n, r, b, en)
+        assert (got.n_units, got.n_rows, got.max_rows_per_dst) == (want.n_units, want.n_rows, want.max_rows_per_dst)
+        for name in ("unit_rel", "unit_cnt", "slot_src", "slot_w", "slot_row"):
+            assert torch.equal(getattr(got, name), getattr(want, name)), (name, transposed)
+        assert len(got.levels) == len(want.levels)
+        for (p1, i1, n1), (p2, i2, n2) in zip(got.levels, want.levels):
+            assert n1 == n2 and torch.equal(p1, p2) and ((i1 is None and i2 is None) or torch.equal(i1, i2))
+        tp = got.as_tile_plan()
+        assert tp.layout == 2 and tp.n_chunks == got.n_units and torch.equal(tp.rel_order, torch.arange(got.n_units, device=dev, dtype=torch.int32))
+    del keep
