@@ -271,7 +271,9 @@ typedef struct rgcn_edge_units {
  * [seg_ptr[i], seg_ptr[i + 1]) into pieces of at most P rows (scaling_rgcn_training_amd/eplan.py segment_levels, P = 256). */
 int rgcn_eplan_segments(const int32_t* slot_row, int64_t n_slots, int32_t n_owned, void* workspace, size_t workspace_bytes,
                         int32_t* seg_ptr, int32_t* seg_idx, void* stream);
-/* z: [n_units * 64, ldz] (rows of unused row tiles are left untouched); packed_w: rgcn_pack_weights(..., transpose) */
+/* z: [n_units * 64, ldz] (rows of unused row tiles are left untouched); packed_w: rgcn_pack_weights(..., transpose).
+ * flags & RGCN_FLAG_SPLIT_PRODUCERS: 64 x 64 layers multiply on bf16 MFMAs over three-way split operands (fp32-equivalent, as
+ * rgcn_fwd under the same flag): the exact-fp32 MFMA rate binds the transform at that width. */
 int rgcn_ep_transform(const rgcn_edge_units_t* units, const float* x, int ldx, int din, const float* packed_w, float* z,
                       int ldz, int dout, unsigned flags, void* stream);
 /* out[i] = sum of rows seg_idx[q] (q itself when seg_idx is NULL) of `in` for q in [seg_ptr[i], seg_ptr[i + 1]), i < n_out,

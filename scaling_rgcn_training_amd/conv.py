@@ -498,8 +498,10 @@ class RGCNConv(nn.Module):
         plans = self._plans(x, edge_index, edge_type)
         flags = self.kernel_flags
         first = (plans.fwd if plans.fwd is not None else plans.bwd) if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
-        if first is not None and self._use_split_producers(first.chunk):
-            flags |= _lib.FLAG_SPLIT_PRODUCERS        # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles; the library falls back where it does not fit
+        if self._use_split_producers(first.chunk if first is not None else 128):
+            # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles / rgcn_ep_transform: the bf16 x 3 (fp32-equivalent) forms of 64 x 64 layers;
+            # the library falls back where they do not fit
+            flags |= _lib.FLAG_SPLIT_PRODUCERS
         return rgcn_conv_function(x, self.weight, self.root, self.bias, plans, self.dist,
                                   _activation, _input_relu, _grad_premasked and _activation == "relu", flags,
                                   comp=self.comp, num_relations=self.num_relations, out_channels=self.out_channels)

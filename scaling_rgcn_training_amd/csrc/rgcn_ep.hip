@@ -115,6 +115,104 @@ __global__ void __launch_bounds__(256) rgcn_ep_transform_kernel(const EpArgs a) 
     }
 }
 
+// 64 x 64 layers on large graphs: the same walk with the contraction on bf16 MFMAs over three-way split operands (the arithmetic of
+// rgcn_tile3p_kernel: x W = (xh + xm + xl)(Wh + Wm + Wl), six products, fp32 accumulation from zero per row tile: fp32-equivalent).
+// Here the wave that multiplies a row tile owns ALL 64 columns of it, so cutting its 16 x 64 values in registers (88 vector
+// instructions) is done once per row, and the relation's three weight planes (96 VGPRs, rgcn_pack3_kernel's fragments) stay in
+// registers over the hundreds of consecutive units a wave walks per relation -- the two costs that sank this form inside the tile
+// kernel do not arise.  48 v_mfma_f32_16x16x32_bf16 of 16 cycles per row tile against 64
+// v_mfma_f32_16x16x4_f32 of 32: the exact-fp32 form is bound by that rate at 64 x 64 (15.2 ms for 110M rows).
+__global__ void __launch_bounds__(256) rgcn_ep_transform3_kernel(const EpArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int u0 = wave * a.units_per_wave;
+    const int u1 = min(u0 + a.units_per_wave, a.n_units);
+    if (u0 >= u1) return;
+    const int row = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    // W planes: packed3[((((rel * 2 + c) * 3 + pl) * 2 + ct) * 2 + s) * 64 + lane]: A operand of Z^T = W^T X^T for columns
+    // 32 c + 16 ct + (lane & 15), k = 32 s + 8 (lane >> 4) + (0..7)
+    const uint4* wp4 = (const uint4*)a.wp + lane;
+    bf16x8 wf[4][3][2];          // [column tile 2 c + ct][plane][k-step]
+    int rel_cur = -1;
+    // this lane's pieces of a gathered row: columns 32 s + 8 kq .. + 7 as two 16-byte loads; beyond the width: zeros
+    unsigned coff[4], rowb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c4 = 8 * (i >> 1) + 2 * kq + (i & 1);          // 16-byte column group: (32 s + 8 kq + 4 h) / 4, i = 2 s + h
+        const bool in = c4 < a.din4;
+        coff[i] = in ? (unsigned)c4 * 16u : 0xFFFFFFF0u;
+        rowb[i] = in ? (unsigned)a.ldx * 4u : 0u;
+    }
+    auto gather = [&](f32x4 (&a4)[4], int src) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a4[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)src, rowb[i]) + coff[i]), 0, 0));
+    };
+    constexpr int px[6] = {0, 0, 1, 0, 2, 1}, pw[6] = {0, 1, 0, 2, 0, 1};      // x plane, W plane: hh hm mh hl lh mm
+    for (int u = u0; u < u1; ++u) {
+        const int rel = ldc(a.unit_rel, u);
+        const int ntile = ldc(a.unit_cnt, u) >> 4;
+        if (rel != rel_cur) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int sk = 0; sk < 2; ++sk)
+                        wf[t4][pl][sk] = __builtin_bit_cast(bf16x8, wp4[((size_t)(((rel * 2 + (t4 >> 1)) * 3 + pl) * 2 + (t4 & 1)) * 2 + sk) * 64]);
+            rel_cur = rel;
+        }
+        const size_t slot0 = (size_t)u * kChunk + row;
+        int src = a.slot_src[slot0];
+        float w = a.slot_w[slot0];
+        f32x4 cur[4];
+        gather(cur, src);
+        for (int t = 0; t < ntile; ++t) {
+            f32x4 nxt[4];
+            float w_n = 0.f;
+            if (t + 1 < ntile) {
+                const int src_n = a.slot_src[slot0 + 16 * (t + 1)];
+                w_n = a.slot_w[slot0 + 16 * (t + 1)];
+                gather(nxt, src_n);
+            }
+            // three round-to-nearest bf16 pieces of the lane's 16 values: xp[plane][k-step] = 8 bf16 of k = 32 s + 8 kq + (0..7)
+            u32x4 xp[3][2];
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    float v0 = cur[2 * sk + (jp >> 1)][2 * (jp & 1)], v1 = cur[2 * sk + (jp >> 1)][2 * (jp & 1) + 1];
+                    const unsigned h = cvt_pk_bf16(v0, v1);
+                    v0 -= __uint_as_float(h << 16);
+                    v1 -= __uint_as_float(h & 0xFFFF0000u);
+                    const unsigned m = cvt_pk_bf16(v0, v1);
+                    v0 -= __uint_as_float(m << 16);
+                    v1 -= __uint_as_float(m & 0xFFFF0000u);
+                    xp[0][sk][jp] = h;
+                    xp[1][sk][jp] = m;
+                    xp[2][sk][jp] = cvt_pk_bf16(v0, v1);
+                }
+            float* zr = a.z + (slot0 + 16 * t) * (size_t)a.ldz + 4 * kq;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t4][pw[q]][sk], __builtin_bit_cast(bf16x8, xp[px[q]][sk]), acc, 0, 0, 0);
+                if (16 * t4 + 4 * kq < a.ldz) *(f32x4*)(zr + 16 * t4) = acc * w;
+            }
+            if (t + 1 < ntile) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+                w = w_n;
+            }
+        }
+    }
+}
+
 // out[i][c] = epilogue(sum over q in [seg_ptr[i], seg_ptr[i + 1]) of in[seg_idx ? seg_idx[q] : q][c]): G = ld4 lanes per
 // segment (one 16-byte piece each), 64 / G segments per wave; the rows of a segment are added in index order.
 // FINAL: + bias, activation, ReLU mask (the layer's output); else the plain sum (a level of a long segment's reduction).
@@ -218,6 +316,12 @@ extern "C" int rgcn_ep_transform(const rgcn_edge_units_t* units, const float* x,
     const int waves = (units->n_units + a.units_per_wave - 1) / a.units_per_wave;
     const int blocks = (waves + 3) / 4;
     hipStream_t s = (hipStream_t)stream;
+    // 64 x 64 on graphs large enough to be bound by the contraction: bf16 x 3 (fp32-equivalent) unless the caller pins exact fp32
+    if (KP == 64 && NP == 64 && a.x_bytes != 0 && (flags & RGCN_FLAG_SPLIT_PRODUCERS) && !(flags & RGCN_FLAG_EXACT_FP32)) {
+        a.wp = packed_w + (size_t)(units->num_relations + 1) * KP * NP;        // the bf16 planes behind the fp32 fragments
+        hipLaunchKernelGGL(rgcn_ep_transform3_kernel, dim3(blocks), dim3(256), 0, s, a);
+        return (int)hipGetLastError();
+    }
     switch (KP) {
         case 16: return ep_dispatch_np<16>(NP, a, blocks, s);
         case 32: return ep_dispatch_np<32>(NP, a, blocks, s);

@@ -72,6 +72,8 @@ def test_ep_matches_golden(dev, golden):
     (3000, 40000, 45, 16, 7, True, 32, 0),              # second layer of the reference's models (hidden 16 -> classes), hubs in levels
     (5000, 120000, 267, 32, 32, False, None, 0),        # AM-like: more relations than rows per tile
     (2000, 150000, 5, 64, 64, True, 64, 0),             # hubs of thousands of rows: three levels
+    (2000, 150000, 5, 64, 64, True, 64, 32),            # RGCN_FLAG_SPLIT_PRODUCERS: the bf16 x 3 transform kernel of 64 x 64 layers
+    (5000, 90000, 40, 50, 64, False, None, 32),         # ... with padded input columns and many relation changes per wave
     (700, 9000, 3, 100, 128, False, None, 0),           # 128-wide: weight fragments reloaded per row tile
     (700, 9000, 3, 128, 33, True, 16, 1),               # RGCN_FLAG_POINTER_GATHER: 64-bit pointer gathers
     (40, 0, 2, 8, 8, False, None, 0),                   # no edges: the root pseudo edges alone
