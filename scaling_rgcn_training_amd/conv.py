@@ -206,9 +206,13 @@ class _RGCNLayerFn(torch.autograd.Function):
             # every rank computes its own blocks straight into the gathered buffer; with destination-range
             # ownership the per-layer all-reduce of SURVEY.md 8e degenerates to an all-gather (each row has
             # exactly one non-zero contributor), issued piece by piece under the next piece's kernels
-            out = _gather_pieces(dctx, [p.fwd for p in plans.pieces],
-                                 lambda pl, rows: _lib.fwd(_lib.plan_struct(pl), xp, din, packed, bs, rows, dout, act, flags),
-                                 ldo, n, x.device)
+            # (a piece whose forward runs the edge-parallel path -- a hub's block -- carries an eplan.EdgePlan instead)
+            def launch_fwd(pl, rows):
+                if isinstance(pl, TilePlan):
+                    _lib.fwd(_lib.plan_struct(pl), xp, din, packed, bs, rows, dout, act, flags)
+                else:
+                    _lib.ep_layer(pl, xp, din, packed, bs, rows, dout, act, None, flags)
+            out = _gather_pieces(dctx, [p.fwd if p.fwd is not None else p.ep_fwd for p in plans.pieces], launch_fwd, ldo, n, x.device)
         ctx.plans, ctx.dctx = plans, dctx
         ctx.dims = (n, din, dout, num_rel)
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
@@ -276,11 +280,13 @@ class _RGCNLayerFn(torch.autograd.Function):
                 dxp = torch.empty(n, ldx, dtype=torch.float32, device=dev)
                 _lib.bwd_dx(_lib.plan_struct(plans.bwd), gp, dout, packed_t, dxp, din, mask, flags)
             else:
-                dxp = _gather_pieces(
-                    dctx, [p.bwd for p in plans.pieces],
-                    lambda pl, rows: _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din,
-                                                 None if mask is None else mask[pl.node_begin:pl.node_end], flags),
-                    ldx, n, dev)
+                def launch_dx(pl, rows):
+                    m = None if mask is None else mask[pl.node_begin:pl.node_end]
+                    if isinstance(pl, TilePlan):
+                        _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din, m, flags)
+                    else:
+                        _lib.ep_layer(pl, gp, dout, packed_t, None, rows, din, _lib.ACT_NONE, m, flags)
+                dxp = _gather_pieces(dctx, [p.bwd if p.bwd is not None else p.ep_bwd for p in plans.pieces], launch_dx, ldx, n, dev)
             dx = dxp if ldx == din else dxp[:, :din]
         if tiles_path:
             # relations: tile-major kernel (gradient rows staged in LDS)
@@ -464,9 +470,14 @@ class RGCNConv(nn.Module):
                 paths = ("ring", "ring")
             return cached_graph_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, chunk=chunk, split=split,
                                       dw_tiles=dw_tiles, paths=paths, widths=(self.in_channels, self.out_channels))
-        # edge-partitioned: every piece on the tile kernels (+ its own tile-major weight-gradient plan)
+        # edge-partitioned: every piece on the kernels the whole graph would take per direction (+ its own tile-major
+        # weight-gradient plan where the forward runs tile kernels)
         from .dist import cached_rank_plans
-        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split, dw_tiles)
+        paths = ("ring", "ring")
+        if x.is_cuda:
+            paths = self.path if self.path == "auto" else ((self.path, self.path) if isinstance(self.path, str) else tuple(self.path))
+        return cached_rank_plans(edge_index, edge_type, n, self.num_relations, tile, self.aggr, self.dist, chunk, split, dw_tiles,
+                                 paths=paths, widths=(self.in_channels, self.out_channels))
 
     def _use_split_producers(self, chunk: int) -> bool:
         from .plan import padded_width
@@ -497,7 +508,10 @@ class RGCNConv(nn.Module):
             raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
         plans = self._plans(x, edge_index, edge_type)
         flags = self.kernel_flags
-        first = (plans.fwd if plans.fwd is not None else plans.bwd) if self.dist is None else (plans.pieces[0].fwd if plans.pieces else None)
+        if self.dist is None:
+            first = plans.fwd if plans.fwd is not None else plans.bwd
+        else:
+            first = next((q for pc in plans.pieces for q in (pc.fwd, pc.bwd) if q is not None), None)
         if self._use_split_producers(first.chunk if first is not None else 128):
             # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles / rgcn_ep_transform: the bf16 x 3 (fp32-equivalent) forms of 64 x 64 layers;
             # the library falls back where they do not fit

@@ -100,7 +100,8 @@ class RankPlans:
 
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
-               aggr: str, dctx: DistContext, chunk: int = 64, split: bool = False, dw_tiles: bool = False) -> RankPlans:
+               aggr: str, dctx: DistContext, chunk: int = 64, split: bool = False, dw_tiles: bool = False,
+               paths=("ring", "ring")) -> RankPlans:
     """Plans of this rank's blocks.  The mean normaliser (a sort of all E keys) is computed ONCE and every piece is
     laid out from the same edge list: on the GPU by the library's plan builder with the piece's node range (it keeps
     the edges that scatter into the range), on the CPU (tests) by the torch form from this rank's share."""
@@ -108,7 +109,7 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
     if edge_type.device.type == "cuda":
         from .plan import build_graph_plans_device
         return RankPlans(build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
-                                                  ranges=[(r, r) for r in ranges], split=split, dw_tiles=dw_tiles))
+                                                  ranges=[(r, r) for r in ranges], split=split, dw_tiles=dw_tiles, paths=paths))
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = edge_type.to(torch.int64)
     w = edge_weights(src, dst, rel, num_relations, aggr)
@@ -132,10 +133,16 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
 
 
 def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext,
-                      chunk: int = 64, split: bool = False, dw_tiles: bool = False) -> RankPlans:
+                      chunk: int = 64, split: bool = False, dw_tiles: bool = False, paths=("ring", "ring"), widths=None) -> RankPlans:
+    def build():
+        p = paths
+        if p == "auto":      # the whole graph's choice per direction (eplan.decide_paths): every rank decides alike
+            from .eplan import decide_paths
+            p = decide_paths(edge_index, n_nodes, num_relations, widths[0], widths[1], tile, chunk)
+        return rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx, chunk, split, dw_tiles, p)
     return cached_graph_plans(
         edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split, dw_tiles=dw_tiles,
-        builder=lambda: rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx, chunk, split, dw_tiles),
+        paths=paths if isinstance(paths, str) else tuple(paths), widths=widths, builder=build,
         extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, tuple(dctx.bounds)))
 
 

@@ -495,6 +495,10 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
     out = []
     for (fb, fe), (bb, be) in rs:
         gp = GraphPlans(fwd=None, bwd=None, num_edges=e)
+        if fe <= fb or be <= bb:       # an empty block of a rank (dist.py)
+            out.append(GraphPlans(fwd=empty_plan(n_nodes, fb, num_relations, tile, chunk, ws.device, int(split)),
+                                  bwd=empty_plan(n_nodes, bb, num_relations, tile, chunk, ws.device, int(split)), num_edges=0))
+            continue
         if paths[0] == "ep":       # edge-parallel direction: relation-major units + destination-major segments (eplan.py)
             from .eplan import build_edge_plan_device
             gp.ep_fwd = build_edge_plan_device(graph, w, False, n_nodes, num_relations, ws, fb, fe)
