@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 13
+#define RGCN_ABI_VERSION 14
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -276,12 +276,12 @@ int rgcn_eplan_segments(const int32_t* slot_row, int64_t n_slots, int32_t n_owne
  * rgcn_fwd under the same flag): the exact-fp32 MFMA rate binds the transform at that width. */
 int rgcn_ep_transform(const rgcn_edge_units_t* units, const float* x, int ldx, int din, const float* packed_w, float* z,
                       int ldz, int dout, unsigned flags, void* stream);
-/* out[i] = sum of rows seg_idx[q] (q itself when seg_idx is NULL) of `in` for q in [seg_ptr[i], seg_ptr[i + 1]), i < n_out,
- * added in index order; final_level != 0: + bias (may be NULL), activation (RGCN_ACT_*), then out *= (mask > 0) when mask
+/* out[i] = sum of rows seg_idx[q] (q itself when seg_idx is NULL) of `in` -- times seg_w[q] when seg_w is given -- for q in
+ * [seg_ptr[i], seg_ptr[i + 1]), i < n_out, added in index order; final_level != 0: + bias (may be NULL), activation (RGCN_ACT_*), then out *= (mask > 0) when mask
  * is given (rows of the layer input when it is a ReLU output, as rgcn_bwd_dx's relu_of).  Long segments are summed in
  * levels: pieces first (final_level = 0, seg_idx of the first level only), the pieces of a segment last. */
-int rgcn_ep_segment_sum(const float* in, int ldin, const int32_t* seg_ptr, const int32_t* seg_idx, int n_out, int width,
-                        const float* bias, int act, const float* mask, int ldm, int final_level, float* out, int ldo,
+int rgcn_ep_segment_sum(const float* in, int ldin, const int32_t* seg_ptr, const int32_t* seg_idx, const float* seg_w, int n_out,
+                        int width, const float* bias, int act, const float* mask, int ldm, int final_level, float* out, int ldo,
                         void* stream);
 
 #ifdef __cplusplus

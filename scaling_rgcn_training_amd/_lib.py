@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
@@ -136,7 +136,7 @@ def load() -> C.CDLL:
     lib.rgcn_ep_transform.restype = i32
     lib.rgcn_ep_transform.argtypes = [C.POINTER(RgcnEdgeUnits), vp, i32, i32, vp, vp, i32, i32, u32, vp]
     lib.rgcn_ep_segment_sum.restype = i32
-    lib.rgcn_ep_segment_sum.argtypes = [vp, i32, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp]
+    lib.rgcn_ep_segment_sum.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp]
     if lib.rgcn_abi_version() != ABI_VERSION:
         raise RgcnLibraryError(f"ABI version mismatch: library {lib.rgcn_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
@@ -389,26 +389,63 @@ def edge_units_struct(ep) -> RgcnEdgeUnits:
     return cached
 
 
+def _edge_units(n_rows_gathered: int, n_units: int, num_relations: int, unit_rel, unit_cnt, slot_src, slot_w) -> RgcnEdgeUnits:
+    return RgcnEdgeUnits(n_rows_gathered, n_units, num_relations, 0, unit_rel.data_ptr(), unit_cnt.data_ptr(), slot_src.data_ptr(),
+                         slot_w.data_ptr())
+
+
+def ep_segment_sum(src: torch.Tensor, ptr: torch.Tensor, idx, w, n_out: int, width: int, out: torch.Tensor, bias=None,
+                   act: int = ACT_NONE, mask=None, final: bool = False) -> None:
+    with torch.cuda.device(src.device):
+        check(load().rgcn_ep_segment_sum(src.data_ptr(), src.stride(0), ptr.data_ptr(), _ptr(idx), _ptr(w), n_out, width,
+                                         _ptr(bias), int(act), _ptr(mask), mask.stride(0) if mask is not None else 0, int(final),
+                                         out.data_ptr(), out.stride(0), _stream(src)), "rgcn_ep_segment_sum")
+
+
+def ep_aggregate_heavy(ep, x: torch.Tensor, din: int) -> Optional[torch.Tensor]:
+    """H[seg] = sum_e w_e x[src_e] over the rows of every heavy (destination, relation) segment of the plan (eplan.HeavyPart):
+    rgcn_ep_segment_sum over x itself, weighted, in levels.  None when the plan has no heavy part."""
+    h = getattr(ep, "heavy", None)
+    if h is None:
+        return None
+    cur = x
+    for ptr, idx, w, n_out in h.levels:
+        dst = torch.empty(max(n_out, 1), x.stride(0), dtype=torch.float32, device=x.device)
+        ep_segment_sum(cur, ptr, idx, w, n_out, din, dst)
+        cur = dst
+    return cur
+
+
 def ep_layer(ep, x: torch.Tensor, din: int, packed: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, dout: int,
-             act: int = ACT_NONE, mask: Optional[torch.Tensor] = None, flags: int = 0) -> None:
-    """out[:n_owned] = act(bias + sum over the plan's rows of w * (x[src] @ W_rel)) * (mask > 0): rgcn_ep_transform, then one
-    rgcn_ep_segment_sum per level of the plan.  ``out``: [n_owned, ld] with ld a multiple of 4."""
+             act: int = ACT_NONE, mask: Optional[torch.Tensor] = None, flags: int = 0) -> Optional[torch.Tensor]:
+    """out[:n_owned] = act(bias + sum over the plan's rows of w * (x[src] @ W_rel)) * (mask > 0): the heavy segments' rows
+    summed first (ep_aggregate_heavy), rgcn_ep_transform over the units (and over the heavy part's pseudo rows, gathered from
+    H), then one rgcn_ep_segment_sum per level of the plan.  ``out``: [n_owned, ld] with ld a multiple of 4.  Returns H (the
+    weight gradients of the heavy part need it) or None."""
     lib = load()
     ldz = out.stride(0)
     st = _stream(x)
+    h = getattr(ep, "heavy", None)
+    hmat = ep_aggregate_heavy(ep, x, din)
     with torch.cuda.device(x.device):
-        z = torch.empty(max(ep.n_units, 1) * 64, ldz, dtype=torch.float32, device=x.device)
+        n_light = ep.n_units * 64
+        z = torch.empty(max(n_light + (h.n_units * 64 if h is not None else 0), 1), ldz, dtype=torch.float32, device=x.device)
         check(lib.rgcn_ep_transform(C.byref(edge_units_struct(ep)), x.data_ptr(), x.stride(0), din, packed.data_ptr(),
                                     z.data_ptr(), ldz, dout, int(flags), st), "rgcn_ep_transform")
-        cur = z
-        for li, (ptr, idx, n_out) in enumerate(ep.levels):
-            final = li == len(ep.levels) - 1
-            dst = out if final else torch.empty(max(n_out, 1), ldz, dtype=torch.float32, device=x.device)
-            check(lib.rgcn_ep_segment_sum(cur.data_ptr(), ldz, ptr.data_ptr(), _ptr(idx), n_out, dout,
-                                          _ptr(bias) if final else None, act if final else ACT_NONE,
-                                          _ptr(mask) if final else None, mask.stride(0) if (final and mask is not None) else 0,
-                                          int(final), dst.data_ptr(), dst.stride(0), st), "rgcn_ep_segment_sum")
-            cur = dst
+        if h is not None:
+            hu = getattr(h, "_cunits", None)
+            if hu is None:
+                hu = h._cunits = _edge_units(h.n_seg, h.n_units, ep.num_relations, h.unit_rel, h.unit_cnt, h.slot_src, h.slot_w)
+            check(lib.rgcn_ep_transform(C.byref(hu), hmat.data_ptr(), hmat.stride(0), din, packed.data_ptr(),
+                                        z[n_light:].data_ptr(), ldz, dout, int(flags), st), "rgcn_ep_transform (heavy part)")
+    cur = z
+    for li, (ptr, idx, n_out) in enumerate(ep.levels):
+        final = li == len(ep.levels) - 1
+        dst = out if final else torch.empty(max(n_out, 1), ldz, dtype=torch.float32, device=x.device)
+        ep_segment_sum(cur, ptr, idx, None, n_out, dout, dst, bias if final else None, act if final else ACT_NONE,
+                       mask if final else None, final)
+        cur = dst
+    return hmat
 
 
 def eplan_segments(slot_row: torch.Tensor, n_owned: int):

@@ -198,7 +198,7 @@ class _RGCNLayerFn(torch.autograd.Function):
         if dctx is None and plans.ep_fwd is not None:
             # edge-parallel path (eplan.py): relation-major dense units -> weighted products per slot -> per-destination sums
             out = torch.empty(n, ldo, dtype=torch.float32, device=x.device)
-            _lib.ep_layer(plans.ep_fwd, xp, din, packed, bs, out, dout, act, None, flags)
+            ctx.ep_heavy = _lib.ep_layer(plans.ep_fwd, xp, din, packed, bs, out, dout, act, None, flags)
         elif dctx is None:
             out = torch.empty(n, ldo, dtype=torch.float32, device=x.device)
             _lib.fwd(_lib.plan_struct(fp), xp, din, packed, bs, out, dout, act, flags)
@@ -315,6 +315,15 @@ class _RGCNLayerFn(torch.autograd.Function):
                     dctx.stats["dw_tiles_pieces"] = dctx.stats.get("dw_tiles_pieces", 0) + 1
                 else:
                     _lib.bwd_dw(_lib.plan_struct(fp), xp, din, gp[b:e], dout, pw, pr, pb, flags)
+                    epf = getattr(pc, "ep_fwd", None)
+                    if need_w and epf is not None and epf.heavy is not None:
+                        # the heavy segments' share: d_W_r += H_seg^T g[dst] over their pseudo rows (H from the forward)
+                        hmat = getattr(ctx, "ep_heavy", None)
+                        if hmat is None:
+                            hmat = _lib.ep_aggregate_heavy(epf, xp, din)
+                        pw2 = torch.empty_like(pw)
+                        _lib.bwd_dw(_lib.plan_struct(epf.heavy_tile_plan()), hmat, din, gp[b:e], dout, pw2, None, None, flags)
+                        pw.add_(pw2)
                 acc = part if acc is None else acc.add_(part)
             if acc is None:
                 acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)

@@ -220,6 +220,7 @@ struct EpSumArgs {
     const float* in;
     const int* seg_ptr;
     const int* seg_idx;
+    const float* seg_w;      // optional weight of every summed row (position q): the pre-aggregation of heavy segments sums w_e x[src_e]
     const float* bias;
     const float* mask;
     float* out;
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256) rgcn_ep_segment_sum_kernel(const EpSumArg
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     auto rowp = [&](int q) { return a.in + (size_t)(a.seg_idx ? a.seg_idx[q] : q) * a.ldin + 4 * piece; };
     int q = q0;
-    if (col_in) {
+    if (col_in && a.seg_w == nullptr) {
         // four rows in flight; the sum order ((r0 + r1) + (r2 + r3)) per group of four, groups in index order, is fixed
         for (; q + 4 <= q1; q += 4) {
             const f32x4 v0 = *(const f32x4*)rowp(q), v1 = *(const f32x4*)rowp(q + 1), v2 = *(const f32x4*)rowp(q + 2),
@@ -247,6 +248,13 @@ __global__ void __launch_bounds__(256) rgcn_ep_segment_sum_kernel(const EpSumArg
             s0 += (v0 + v1) + (v2 + v3);
         }
         for (; q < q1; ++q) s1 += *(const f32x4*)rowp(q);
+    } else if (col_in) {
+        for (; q + 4 <= q1; q += 4) {
+            const f32x4 v0 = *(const f32x4*)rowp(q) * a.seg_w[q], v1 = *(const f32x4*)rowp(q + 1) * a.seg_w[q + 1],
+                        v2 = *(const f32x4*)rowp(q + 2) * a.seg_w[q + 2], v3 = *(const f32x4*)rowp(q + 3) * a.seg_w[q + 3];
+            s0 += (v0 + v1) + (v2 + v3);
+        }
+        for (; q < q1; ++q) s1 += *(const f32x4*)rowp(q) * a.seg_w[q];
     }
     f32x4 v = s0 + s1;
     (void)s2; (void)s3;
@@ -331,8 +339,8 @@ extern "C" int rgcn_ep_transform(const rgcn_edge_units_t* units, const float* x,
     return RGCN_ERR_WIDTH;
 }
 
-extern "C" int rgcn_ep_segment_sum(const float* in, int ldin, const int32_t* seg_ptr, const int32_t* seg_idx, int n_out,
-                                   int width, const float* bias, int act, const float* mask, int ldm, int final_level,
+extern "C" int rgcn_ep_segment_sum(const float* in, int ldin, const int32_t* seg_ptr, const int32_t* seg_idx, const float* seg_w,
+                                   int n_out, int width, const float* bias, int act, const float* mask, int ldm, int final_level,
                                    float* out, int ldo, void* stream) {
     if (!in || !seg_ptr || !out) return RGCN_ERR_NULL;
     if (n_out < 0) return RGCN_ERR_PLAN;
@@ -347,6 +355,7 @@ extern "C" int rgcn_ep_segment_sum(const float* in, int ldin, const int32_t* seg
     a.in = in;
     a.seg_ptr = seg_ptr;
     a.seg_idx = seg_idx;
+    a.seg_w = seg_w;
     a.bias = bias;
     a.mask = mask;
     a.out = out;

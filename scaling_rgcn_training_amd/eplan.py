@@ -37,6 +37,25 @@ from torch import Tensor
 
 UNIT = 64          # slots per unit (== plan.UNIT: what the weight-gradient kernels walk)
 PIECE = 256        # rows one lane group sums in a row before the sum goes through another level
+HEAVY = 16         # rows of one (destination, relation) segment from which the segment is aggregated BEFORE the transform
+
+
+@dataclass
+class HeavyPart:
+    """Aggregate-then-transform for the (destination, relation) segments that hold at least HEAVY rows (a hub's): the rows of
+    such a segment share the weight matrix, so sum_e w_e (x[src_e] @ W_r) = (sum_e w_e x[src_e]) @ W_r -- their gathered rows are
+    summed first (rgcn_ep_segment_sum over x itself, weighted, in levels), and ONE pseudo row per segment goes through the
+    transform, the per-destination sums and the weight gradients (d_W_r += H_seg^T g[dst]).  S << E is the regime of the
+    reference's summary graphs (graphs/AIFB/attr/sum/AIFB_sum_in.nt: 49,838 edges, at most 44 x 89 segments)."""
+    n_seg: int
+    levels: list            # [(seg_ptr int32, seg_idx int32 or None, seg_w float32 or None, n_out)]: level 0 gathers rows of x
+    n_units: int
+    unit_rel: Tensor
+    unit_cnt: Tensor
+    slot_src: Tensor        # pseudo rows gather row `segment id` of the aggregated matrix H (padding: n_seg)
+    slot_w: Tensor          # 1 (the rows' weights went into H)
+    slot_row: Tensor
+    _tile_plan: object = field(default=None, repr=False)
 
 
 @dataclass
@@ -52,8 +71,10 @@ class EdgePlan:
     slot_src: Tensor        # int32 [n_units * 64]  row to gather (padding: n_nodes -> zeros)
     slot_w: Tensor          # float32 [n_units * 64] (padding: 0)
     slot_row: Tensor        # int32 [n_units * 64]  destination row inside the owned range (padding: n_owned)
-    levels: List[Tuple[Tensor, Optional[Tensor], int]]   # per level (seg_ptr int32 [n_out + 1], seg_idx int32 or None, n_out)
+    levels: List[Tuple[Tensor, Optional[Tensor], int]]   # per level (seg_ptr int32 [n_out + 1], seg_idx int32 or None, n_out);
+                            # level 0 indexes the rows of Z = [the units' slots; the heavy part's slots]
     max_rows_per_dst: int
+    heavy: Optional[HeavyPart] = None
     _tile_plan: object = field(default=None, repr=False)
 
     @property
@@ -70,7 +91,28 @@ class EdgePlan:
             ts.append(p)
             if i is not None:
                 ts.append(i)
+        if self.heavy is not None:
+            h = self.heavy
+            ts += [h.unit_rel, h.unit_cnt, h.slot_src, h.slot_w, h.slot_row] + [t for lv in h.levels for t in lv[:3] if t is not None]
         return sum(t.numel() * t.element_size() for t in ts)
+
+    def heavy_tile_plan(self):
+        """the heavy part's pseudo rows as a layout-2 plan for rgcn_bwd_dw (its gathered matrix is the aggregated H)"""
+        h = self.heavy
+        if h._tile_plan is None:
+            from .plan import TilePlan
+            dev = self.device
+            n_own = self.n_owned
+            tile = min(32768, (n_own + 15) // 16 * 16)
+            n_tiles = (n_own + tile - 1) // tile
+            z = torch.zeros(h.n_units, dtype=torch.int32, device=dev)
+            h._tile_plan = TilePlan(
+                n_nodes=h.n_seg, node_begin=self.node_begin, node_end=self.node_end, num_relations=self.num_relations, tile=tile,
+                chunk=UNIT, n_tiles=n_tiles, n_chunks=h.n_units, n_edges=h.n_seg,
+                tile_ptr=torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev), chunk_rel=h.unit_rel, chunk_cnt=h.unit_cnt,
+                chunk_tile=z, chunk_flags=z, rel_order=torch.arange(h.n_units, dtype=torch.int32, device=dev), slot_src=h.slot_src,
+                slot_w=h.slot_w, slot_dstl=None, slot_row=h.slot_row, slot_acc=h.slot_row, layout=2)
+        return h._tile_plan
 
     def as_tile_plan(self):
         """The units as a plan.TilePlan the relation-major weight-gradient kernels accept (plan layout 2: they read
@@ -116,10 +158,79 @@ def segment_levels(counts: Tensor, piece: int = PIECE):
         cnt = npieces
 
 
+def heavy_mask(scatter: Tensor, rel: Tensor, n_nodes: int, threshold: int) -> Optional[Tensor]:
+    """bool [E]: the edge belongs to a (scatter node, relation) segment of at least ``threshold`` edges (duplicates counted);
+    None when there is no such segment.  One sort of the E segment keys, at plan time."""
+    if threshold <= 0 or scatter.numel() == 0:
+        return None
+    key = rel.to(torch.int64) * n_nodes + scatter.to(torch.int64)
+    _, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+    if int(cnt.max()) < threshold:
+        return None
+    return cnt[inv] >= threshold
+
+
+def build_heavy_part(gather: Tensor, loc: Tensor, rel: Tensor, w: Tensor, n_own: int, num_relations: int, piece: int) -> HeavyPart:
+    """gather / loc (scatter row inside the owned range) / rel / w of the edges of the heavy segments."""
+    dev = gather.device
+    key = rel.to(torch.int64) * max(n_own, 1) + loc.to(torch.int64)
+    ukey, seg = torch.unique(key, return_inverse=True)                 # segments sorted by (relation, destination)
+    n_seg = int(ukey.shape[0])
+    order = torch.sort(seg * (int(gather.max()) + 1 if gather.numel() else 1) + gather.to(torch.int64))[1]      # rows by (segment, gathered row)
+    idx0 = gather[order].to(torch.int32)
+    w0 = w[order].to(torch.float32)
+    cnt = torch.bincount(seg, minlength=n_seg)
+    lv = segment_levels(cnt, piece)
+    levels = [(p.to(torch.int32), idx0 if i == 0 else None, w0 if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
+    # one pseudo row per segment, relation-major in dense units (sequential placement)
+    prel = ukey // max(n_own, 1)
+    pdst = ukey % max(n_own, 1)
+    r1 = num_relations + 1
+    rcnt = torch.bincount(prel, minlength=r1)
+    runits = (rcnt + UNIT - 1) // UNIT
+    ubase = torch.cumsum(runits, 0) - runits
+    rstart = torch.cumsum(rcnt, 0) - rcnt
+    n_units = int(runits.sum())
+    slot = ubase[prel] * UNIT + (torch.arange(n_seg, device=dev) - rstart[prel])
+    slot_src = torch.full((n_units * UNIT,), n_seg, dtype=torch.int32, device=dev)
+    slot_w = torch.zeros(n_units * UNIT, dtype=torch.float32, device=dev)
+    slot_row = torch.full((n_units * UNIT,), n_own, dtype=torch.int32, device=dev)
+    slot_src[slot] = torch.arange(n_seg, device=dev, dtype=torch.int32)
+    slot_w[slot] = 1.0
+    slot_row[slot] = pdst.to(torch.int32)
+    unit_rel = torch.repeat_interleave(torch.arange(r1, device=dev), runits).to(torch.int32)
+    uidx = torch.arange(n_units, device=dev) - ubase[unit_rel.long()]
+    used = torch.clamp(rcnt[unit_rel.long()] - uidx * UNIT, max=UNIT)
+    unit_cnt = ((used + 15) // 16 * 16).to(torch.int32)
+    return HeavyPart(n_seg=n_seg, levels=levels, n_units=n_units, unit_rel=unit_rel, unit_cnt=unit_cnt, slot_src=slot_src,
+                     slot_w=slot_w, slot_row=slot_row)
+
+
+def _finish_levels(slot_row_light: Tensor, heavy: Optional[HeavyPart], n_own: int, piece: int, on_device: bool):
+    """destination-major index over Z = [light slots; heavy slots] and its sum levels"""
+    rows = slot_row_light if heavy is None else torch.cat([slot_row_light, heavy.slot_row])
+    if on_device:
+        from . import _lib
+        seg_ptr, seg_idx = _lib.eplan_segments(rows, n_own)
+        n_rows = int(seg_ptr[-1])
+        seg_idx = seg_idx[:n_rows]
+        counts = (seg_ptr[1:] - seg_ptr[:-1]).to(torch.int64)
+    else:
+        n_slots = int(rows.numel())
+        real = torch.nonzero(rows < n_own).squeeze(1)
+        seg_idx = (torch.sort(rows[real].to(torch.int64) * max(n_slots, 1) + real)[0] % max(n_slots, 1)).to(torch.int32)
+        counts = torch.bincount(rows[real].to(torch.int64), minlength=n_own)
+        n_rows = int(real.numel())
+    lv = segment_levels(counts, piece)
+    levels = [(p.to(torch.int32), seg_idx if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
+    return levels, n_rows, (int(counts.max()) if n_own else 0)
+
+
 def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes: int, num_relations: int,
-                    node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE) -> EdgePlan:
+                    node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE, heavy: int = 0) -> EdgePlan:
     """gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src); w: the edge weights of
-    plan.edge_weights (1 / max(1, c[dst, rel]) for aggr = 'mean'), kept for both directions."""
+    plan.edge_weights (1 / max(1, c[dst, rel]) for aggr = 'mean'), kept for both directions.  heavy: segments of at least
+    that many rows are aggregated before the transform (HeavyPart); 0: every row goes through the transform."""
     if node_end is None:
         node_end = n_nodes
     dev = gather.device
@@ -134,6 +245,11 @@ def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_n
     own = (scatter >= node_begin) & (scatter < node_end)
     if not bool(own.all()):
         gather, scatter, rel, w = gather[own], scatter[own], rel[own], w[own]
+    hp = None
+    hm = heavy_mask(scatter, rel, n_nodes, heavy)
+    if hm is not None:
+        hp = build_heavy_part(gather[hm], scatter[hm] - node_begin, rel[hm], w[hm], n_own, num_relations, piece)
+        gather, scatter, rel, w = gather[~hm], scatter[~hm], rel[~hm], w[~hm]
     nodes = torch.arange(node_begin, node_end, device=dev, dtype=torch.int64)
     g_all = torch.cat([gather, nodes])
     loc = torch.cat([scatter, nodes]) - node_begin
@@ -173,40 +289,48 @@ def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_n
     uidx = torch.arange(n_units, device=dev) - ubase[unit_rel.long()]
     unit_cnt = (torch.clamp(rnt[unit_rel.long()] - uidx * (UNIT // 16), max=UNIT // 16) * 16).to(torch.int32)
     # destination-major index over the slots, a destination's rows in slot order (= relation-major): rgcn_eplan_segments
-    seg_idx = torch.sort(loc * max(n_slots, 1) + slot)[0] % max(n_slots, 1)
-    seg_idx = seg_idx.to(torch.int32)
-    dcnt = torch.bincount(loc, minlength=n_own)
-    lv = segment_levels(dcnt, piece)
-    levels = [(p.to(torch.int32), seg_idx if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
+    levels, n_all, max_rows = _finish_levels(slot_row, hp, n_own, piece, False)
     return EdgePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, n_units=n_units,
                     n_rows=n_rows, unit_rel=unit_rel, unit_cnt=unit_cnt, slot_src=slot_src, slot_w=slot_w, slot_row=slot_row,
-                    levels=levels, max_rows_per_dst=int(dcnt.max()) if n_own else 0)
+                    levels=levels, max_rows_per_dst=max_rows, heavy=hp)
 
 
 def build_edge_plan_device(graph, w: Tensor, transposed: bool, n_nodes: int, num_relations: int, ws: Tensor,
-                           node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE) -> EdgePlan:
+                           node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE, heavy: int = 0,
+                           edge_index: Optional[Tensor] = None, edge_type: Optional[Tensor] = None) -> EdgePlan:
     """The same plan by the library's own builder (csrc/rgcn_plan.hip): rgcn_plan_build_begin / _finish with layout 2 lay the
     owned range out as one relation-major "tile", rgcn_eplan_segments sorts the slots by destination; only the sum levels of
-    hubs (arithmetic on seg_ptr) stay here.  graph / w / ws: _lib.graph_struct, _lib.edge_weights, _lib.plan_workspace."""
+    hubs (arithmetic on seg_ptr) and the split-off of the heavy segments (``heavy`` > 0; needs the COO tensors) stay here.
+    graph / w / ws: _lib.graph_struct, _lib.edge_weights, _lib.plan_workspace."""
     from . import _lib
     if node_end is None:
         node_end = n_nodes
     n_own = node_end - node_begin
+    hp, keep = None, None
+    if heavy > 0 and edge_index is not None and int(edge_type.shape[0]) > 0:
+        g_, s_ = (edge_index[1], edge_index[0]) if transposed else (edge_index[0], edge_index[1])
+        own = (s_ >= node_begin) & (s_ < node_end)
+        hm = heavy_mask(torch.where(own, s_, torch.full_like(s_, -1)), edge_type, n_nodes + 1, heavy)      # (-1: not owned, its own keys)
+        if hm is not None:
+            hm = hm & own
+            if bool(hm.any()):
+                hp = build_heavy_part(g_[hm], s_[hm] - node_begin, edge_type[hm], w[hm], n_own, num_relations, piece)
+                lm = ~hm
+                ei_l, et_l, w = edge_index[:, lm].contiguous(), edge_type[lm].contiguous(), w[lm].contiguous()
+                graph, keep = _lib.graph_struct(ei_l, et_l, n_nodes, num_relations)
     ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, 16, UNIT, ws, 2)
-    seg_ptr, seg_idx = _lib.eplan_segments(a["slot_row"], n_own)
-    counts = (seg_ptr[1:] - seg_ptr[:-1]).to(torch.int64)
-    n_rows = int(seg_ptr[-1])
-    lv = segment_levels(counts, piece)
-    levels = [(p.to(torch.int32), seg_idx[:n_rows] if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
+    levels, n_all, max_rows = _finish_levels(a["slot_row"], hp, n_own, piece, True)
+    n_rows = n_all - (hp.n_seg if hp is not None else 0)
     ep = EdgePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, n_units=int(ps.n_chunks),
                   n_rows=n_rows, unit_rel=a["chunk_rel"], unit_cnt=a["chunk_cnt"], slot_src=a["slot_src"], slot_w=a["slot_w"],
-                  slot_row=a["slot_row"], levels=levels, max_rows_per_dst=int(counts.max()) if n_own else 0)
+                  slot_row=a["slot_row"], levels=levels, max_rows_per_dst=max_rows, heavy=hp)
     # the same arrays are the relation-major walk of the weight-gradient kernels: the struct the builder filled
     from .plan import TilePlan
     tp = TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, tile=int(ps.tile),
                   chunk=UNIT, n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None, layout=2, **a)
     tp._cstruct = ps
     ep._tile_plan = tp
+    del keep
     return ep
 
 

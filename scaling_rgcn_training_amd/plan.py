@@ -434,12 +434,13 @@ def build_graph_plans_torch(edge_index: Tensor, edge_type: Tensor, n_nodes: int,
     fb, fe = fwd_range if fwd_range is not None else (0, n_nodes)
     bb, be = bwd_range if bwd_range is not None else (0, n_nodes)
     gp = GraphPlans(fwd=None, bwd=None, num_edges=int(edge_type.shape[0]))
+    from .eplan import HEAVY
     if paths[0] == "ep":
-        gp.ep_fwd = build_edge_plan(src, dst, edge_type, w, n_nodes, num_relations, fb, fe)
+        gp.ep_fwd = build_edge_plan(src, dst, edge_type, w, n_nodes, num_relations, fb, fe, heavy=HEAVY)
     else:
         gp.fwd = build_plan(src, dst, edge_type, w, n_nodes, num_relations, tile, fb, fe, chunk, split)
     if paths[1] == "ep":
-        gp.ep_bwd = build_edge_plan(dst, src, edge_type, w, n_nodes, num_relations, bb, be)
+        gp.ep_bwd = build_edge_plan(dst, src, edge_type, w, n_nodes, num_relations, bb, be, heavy=HEAVY)
     else:
         gp.bwd = build_plan(dst, src, edge_type, w, n_nodes, num_relations, tile, bb, be, chunk, split)
     return gp
@@ -492,6 +493,8 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
         if "out of range" in str(err):
             raise ValueError("edge_index / edge_type out of range [0, num_nodes) / [0, num_relations)") from err
         raise
+    from .eplan import HEAVY
+    heavy = HEAVY if ranges is None else 0        # (a rank's pieces: every row through the transform)
     out = []
     for (fb, fe), (bb, be) in rs:
         gp = GraphPlans(fwd=None, bwd=None, num_edges=e)
@@ -501,14 +504,16 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
             continue
         if paths[0] == "ep":       # edge-parallel direction: relation-major units + destination-major segments (eplan.py)
             from .eplan import build_edge_plan_device
-            gp.ep_fwd = build_edge_plan_device(graph, w, False, n_nodes, num_relations, ws, fb, fe)
+            gp.ep_fwd = build_edge_plan_device(graph, w, False, n_nodes, num_relations, ws, fb, fe, heavy=heavy,
+                                               edge_index=edge_index, edge_type=edge_type)
         else:
             gp.fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws, split)
             if ranges is not None:
                 gp.num_edges = gp.fwd.n_edges
         if paths[1] == "ep":
             from .eplan import build_edge_plan_device
-            gp.ep_bwd = build_edge_plan_device(graph, w, True, n_nodes, num_relations, ws, bb, be)
+            gp.ep_bwd = build_edge_plan_device(graph, w, True, n_nodes, num_relations, ws, bb, be, heavy=heavy,
+                                               edge_index=edge_index, edge_type=edge_type)
         else:
             gp.bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
         if dw_tiles and paths[0] != "ep" and fe > fb:

@@ -21,6 +21,23 @@ def emulate_ep(ep, x, w_all, bias=None):
         m = (rel == r) & used
         z[m] = (xr[src[m]] @ w_all[r]) * sw[m][:, None]
     z[~used] = np.nan                                                     # never written by the kernel, never read by the sums
+    if ep.heavy is not None:                                              # heavy segments: rows summed first, one pseudo row each
+        h = ep.heavy
+        cur = x
+        for ptr, idx, w, n_out in h.levels:
+            ptr = ptr.numpy()
+            ii = idx.numpy() if idx is not None else np.arange(int(ptr[-1]))
+            ww = w.numpy().astype(np.float64)[:, None] if w is not None else 1.0
+            rows = cur[ii] * ww
+            cur = np.stack([rows[ptr[i]:ptr[i + 1]].sum(0) for i in range(n_out)]) if n_out else np.zeros((0, x.shape[1]))
+        hr = np.concatenate([cur, np.zeros((1, x.shape[1]))], 0)
+        zh = np.full((h.n_units * 64, w_all.shape[2]), np.nan)
+        hrel = np.repeat(h.unit_rel.numpy(), 64)
+        hused = (np.arange(64)[None, :] < h.unit_cnt.numpy()[:, None]).reshape(-1)
+        for r in range(w_all.shape[0]):
+            m = (hrel == r) & hused
+            zh[m] = (hr[h.slot_src.numpy()[m]] @ w_all[r]) * h.slot_w.numpy().astype(np.float64)[m][:, None]
+        z = np.concatenate([z, zh], 0)
     cur = z
     for ptr, idx, n_out in ep.levels:
         ptr = ptr.numpy()
@@ -107,3 +124,43 @@ def test_choose_path_picks_the_edge_parallel_path_for_the_reference_shapes():
     assert E.choose_path(10_000_000, 100_000_000, 32, 64, 64, 224, 128, 66_000_000) == "ep"       # Zipf hubs: two thirds of the edges in one tile
     ei = torch.stack([torch.randint(0, 8243, (49838,)), torch.randint(0, 8243, (49838,))])
     assert E.decide_paths(ei, 8243, 89, 63, 16, 512, 64) == ("ep", "ep")
+
+
+@pytest.mark.parametrize("threshold", [2, 16])
+def test_heavy_segments_are_aggregated_before_the_transform(golden, threshold):
+    """eplan.HeavyPart: the (destination, relation) segments with at least `threshold` rows leave the units, their rows are summed
+    first (weighted, in levels) and one pseudo row per segment takes their place -- same outputs, same weight gradients."""
+    if str(golden["mode"]) != "full":
+        pytest.skip("plan is weight-mode independent")
+    f = lambda k: torch.from_numpy(golden[k])
+    n, r = int(golden["num_nodes"]), int(golden["num_relations"])
+    ei, et = f("edge_index").long(), f("edge_type").long()
+    w = P.edge_weights(ei[0], ei[1], et, r)
+    w_all = np.concatenate([golden["weight"], golden["root"][None]], 0).astype(np.float64)
+    for g_, s_, xin, ref in ((ei[0], ei[1], golden["x"], golden["out"] - golden["bias"]), (ei[1], ei[0], golden["dout"], golden["d_x"])):
+        ep = E.build_edge_plan(g_, s_, et, w, n, r, piece=8, heavy=threshold)
+        plain = E.build_edge_plan(g_, s_, et, w, n, r, piece=8)
+        key = et * n + s_
+        cnt = torch.unique(key, return_counts=True)[1]
+        if int(cnt.max()) < threshold:
+            assert ep.heavy is None
+            continue
+        h = ep.heavy
+        assert h.n_seg == int((cnt >= threshold).sum())
+        assert int((h.levels[0][0][1:] - h.levels[0][0][:-1]).sum()) == int(cnt[cnt >= threshold].sum())     # every heavy edge summed once
+        assert ep.n_rows < plain.n_rows
+        wm = w_all if xin is golden["x"] else np.transpose(w_all, (0, 2, 1))
+        np.testing.assert_allclose(emulate_ep(ep, xin.astype(np.float64), wm), ref, rtol=1e-6, atol=1e-6)
+    # weight gradients: the light units over x + the pseudo rows over H
+    ep = E.build_edge_plan(ei[0], ei[1], et, w, n, r, heavy=threshold)
+    dw = emulate_dw(ep.as_tile_plan(), golden["x"], golden["dout"], w_all.shape[0], w_all.shape[1], w_all.shape[2])
+    if ep.heavy is not None:
+        h = ep.heavy
+        cur = golden["x"].astype(np.float64)
+        for ptr, idx, ww, n_out in h.levels:
+            ptr = ptr.numpy()
+            ii = idx.numpy() if idx is not None else np.arange(int(ptr[-1]))
+            rows = cur[ii] * (ww.numpy().astype(np.float64)[:, None] if ww is not None else 1.0)
+            cur = np.stack([rows[ptr[i]:ptr[i + 1]].sum(0) for i in range(n_out)])
+        dw = dw + emulate_dw(ep.heavy_tile_plan(), cur, golden["dout"], w_all.shape[0], w_all.shape[1], w_all.shape[2])
+    np.testing.assert_allclose(dw[:-1], golden["d_wfull"], rtol=1e-6, atol=1e-6)

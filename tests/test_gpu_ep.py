@@ -18,14 +18,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=None, flags=0):
+def _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=None, flags=0, heavy=0):
     """forward, dX (edge-parallel kernels) and dW / dRoot / db (relation-major kernels on the plan's dense units)"""
     from scaling_rgcn_training_amd import _lib, eplan as E, plan as P
     from scaling_rgcn_training_amd.conv import _rows16, _round4
     din, dout = w.shape[1], w.shape[2]
     eid, etd = ei.to(dev), et.to(dev)
     wgt = P.edge_weights(eid[0], eid[1], etd, r)
-    kw = {} if piece is None else {"piece": piece}
+    kw = {"heavy": heavy} if piece is None else {"piece": piece, "heavy": heavy}
     fwd = E.build_edge_plan(eid[0], eid[1], etd, wgt, n, r, **kw)
     bwd = E.build_edge_plan(eid[1], eid[0], etd, wgt, n, r, **kw)
     xd, gd = _rows16(x.to(dev), din), _rows16(dg.to(dev), dout)
@@ -39,6 +39,10 @@ def _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=None, flags=0):
     dr = torch.full((din, dout), float("nan"), device=dev)
     db = torch.full((dout,), float("nan"), device=dev)
     _lib.bwd_dw(_lib.plan_struct(fwd.as_tile_plan()), xd, din, gd, dout, dw, dr, db, flags)
+    if fwd.heavy is not None:       # the heavy segments' pseudo rows over the aggregated matrix H
+        dw2 = torch.empty_like(dw)
+        _lib.bwd_dw(_lib.plan_struct(fwd.heavy_tile_plan()), _lib.ep_aggregate_heavy(fwd, xd, din), din, gd, dout, dw2, None, None, flags)
+        dw += dw2
     torch.cuda.synchronize()
     return (out[:, :dout].cpu().numpy(), dx[:, :din].cpu().numpy(), dw.cpu().numpy(), dr.cpu().numpy(), db.cpu().numpy()), fwd
 
@@ -60,13 +64,14 @@ def test_ep_matches_golden(dev, golden):
         pytest.skip("weight modes go through the module (test_gpu_shapes)")
     f = lambda k: torch.from_numpy(golden[k])
     n, r = int(golden["num_nodes"]), int(golden["num_relations"])
-    res, ep = _ep_layer(dev, f("edge_index").long(), f("edge_type").long(), n, r, f("x"), f("weight"), f("root"), f("bias"), f("dout"))
+    res, ep = _ep_layer(dev, f("edge_index").long(), f("edge_type").long(), n, r, f("x"), f("weight"), f("root"), f("bias"), f("dout"), heavy=16)
     x, dg = f("x"), f("dout")
     ei, et = f("edge_index").long(), f("edge_type").long()
     ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), golden["weight"], golden["root"], golden["bias"], dg.numpy())
     _check(res, ref, gr, x, ei, et, f("weight"), f("root"), f("bias"), dg, f" [golden n{n}]")
 
 
+@pytest.mark.parametrize("heavy", [0, 16], ids=["per-row", "heavy-segments-aggregated"])
 @pytest.mark.parametrize("n,e,r,din,dout,skew,piece,flags", [
     (8243, 49838, 89, 63, 16, False, None, 0),          # AIFB shape
     (3000, 40000, 45, 16, 7, True, 32, 0),              # second layer of the reference's models (hidden 16 -> classes), hubs in levels
@@ -78,7 +83,7 @@ def test_ep_matches_golden(dev, golden):
     (700, 9000, 3, 128, 33, True, 16, 1),               # RGCN_FLAG_POINTER_GATHER: 64-bit pointer gathers
     (40, 0, 2, 8, 8, False, None, 0),                   # no edges: the root pseudo edges alone
 ])
-def test_ep_matches_oracle(dev, n, e, r, din, dout, skew, piece, flags):
+def test_ep_matches_oracle(dev, n, e, r, din, dout, skew, piece, flags, heavy):
     ei, et = O.synthetic_graph(n, max(e, 1), r, seed=n + r, skew=skew)
     if e == 0:
         ei, et = ei[:, :0], et[:0]
@@ -91,11 +96,13 @@ def test_ep_matches_oracle(dev, n, e, r, din, dout, skew, piece, flags):
     x = torch.randn(n, din, generator=g)
     dg = torch.randn(n, dout, generator=g)
     ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
-    res, ep = _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=piece, flags=flags)
+    res, ep = _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=piece, flags=flags, heavy=heavy)
     if piece is not None and ep.max_rows_per_dst > piece:
         assert len(ep.levels) >= 2
-    _check(res, ref, gr, x, ei, et, w, root, bias, dg, f" [n{n} r{r} {din}->{dout}]")
-    again, _ = _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=piece, flags=flags)
+    if heavy and skew and e > 0:
+        assert ep.heavy is not None and ep.heavy.n_seg > 0, "a hub graph has segments of 16 rows and more"
+    _check(res, ref, gr, x, ei, et, w, root, bias, dg, f" [n{n} r{r} {din}->{dout} heavy {heavy}]")
+    again, _ = _ep_layer(dev, ei, et, n, r, x, w, root, bias, dg, piece=piece, flags=flags, heavy=heavy)
     assert all(np.array_equal(a, b) for a, b in zip(res, again)), "bit-reproducible"
 
 
@@ -179,10 +186,17 @@ def test_device_edge_plan_is_bit_identical_to_the_torch_twin(dev, n, e, r, skew,
     graph, keep = _lib.graph_struct(eid, etd, n, r)
     ws = _lib.plan_workspace(int(etd.shape[0]), en - b, r, 16, dev)
     w = _lib.edge_weights(graph, "mean", ws)
-    for transposed in (False, True):
-        got = E.build_edge_plan_device(graph, w, transposed, n, r, ws, b, en)
+    for transposed, heavy in ((False, 0), (True, 0), (False, 16), (True, 16)):
+        got = E.build_edge_plan_device(graph, w, transposed, n, r, ws, b, en, heavy=heavy, edge_index=eid, edge_type=etd)
         g_, s_ = (eid[1], eid[0]) if transposed else (eid[0], eid[1])
-        want = E.build_edge_plan(g_, s_, etd, w, n, r, b, en)
+        want = E.build_edge_plan(g_, s_, etd, w, n, r, b, en, heavy=heavy)
+        assert (got.heavy is None) == (want.heavy is None)
+        if got.heavy is not None:
+            assert (got.heavy.n_seg, got.heavy.n_units) == (want.heavy.n_seg, want.heavy.n_units)
+            for name in ("unit_rel", "unit_cnt", "slot_src", "slot_w", "slot_row"):
+                assert torch.equal(getattr(got.heavy, name), getattr(want.heavy, name)), ("heavy " + name, transposed)
+            for l1, l2 in zip(got.heavy.levels, want.heavy.levels):
+                assert all((a is None and b_ is None) or (torch.is_tensor(a) and torch.equal(a, b_)) or a == b_ for a, b_ in zip(l1, l2))
         assert (got.n_units, got.n_rows, got.max_rows_per_dst) == (want.n_units, want.n_rows, want.max_rows_per_dst)
         for name in ("unit_rel", "unit_cnt", "slot_src", "slot_w", "slot_row"):
             assert torch.equal(getattr(got, name), getattr(want, name)), (name, transposed)

@@ -110,10 +110,13 @@ def test_full_size_sampled_rows_match_oracle(big):
     refx, condx = _sample_reference(big, rows, "dx")
     assert_close(xg.grad[rows].cpu().numpy(), refx, condx, "dX rows")
     if big["kind"] == "skew":
-        # the ten destinations with the most in-edges (millions of rows each: the per-destination sums go through levels)
+        # the ten destinations with the most in-edges (millions of rows each: their (destination, relation) segments are summed in
+        # levels BEFORE the transform, one pseudo row per segment goes through it)
         from scaling_rgcn_training_amd.plan import cached_graph_plans
         plans = conv._plans(xg, big["ei"], big["et"])
-        assert plans.ep_fwd is not None and len(plans.ep_fwd.levels) >= 3, "the hub graph's forward runs the edge-parallel path"
+        epf = plans.ep_fwd
+        assert epf is not None and epf.heavy is not None, "the hub graph's forward runs the edge-parallel path, its hubs pre-aggregated"
+        assert len(epf.heavy.levels) >= 3, "segments of hundreds of thousands of rows are summed in levels"
         deg = torch.bincount(big["ei"][1], minlength=N)
         hubs = torch.topk(deg, 10).indices.tolist()
         for h in hubs:
