@@ -494,7 +494,7 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
             raise ValueError("edge_index / edge_type out of range [0, num_nodes) / [0, num_relations)") from err
         raise
     from .eplan import HEAVY
-    heavy = HEAVY if ranges is None else 0        # (a rank's pieces: every row through the transform)
+    heavy = HEAVY
     out = []
     for (fb, fe), (bb, be) in rs:
         gp = GraphPlans(fwd=None, bwd=None, num_edges=e)
