@@ -476,7 +476,11 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
                         for (int ct = 0; ct < NCT; ++ct)
                             *(f32x4*)(dst[step - 1] + 16 * ct) = y[step - 1][ct] * o[step - 1].w1 + old[step - 1][ct];
                     }
-                    if (step < NRT && !(RGCN_P3_ABL & 4)) {
+                    if (step == NRT - 1 && (RGCN_P3_ABL & 128)) {      // timing only: the LAST row tile's accumulator row is not read
+                        dst[step] = acc_ptr(o[step].d1, col4_bytes);
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) old[step][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else if (step < NRT && !(RGCN_P3_ABL & 4)) {
                         // (RGCN_P3_ABL & 64, timing only, wrong results: the 16 lanes of a phase address rows that differ mod
                         // 16 -- what a conflict-free accumulator order could buy)
                         dst[step] = acc_ptr((RGCN_P3_ABL & 64) ? ((o[step].d1 & 0xFFFFF0) | rowl) : o[step].d1, col4_bytes);
