@@ -49,6 +49,21 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 
+// x = h + m + l with three round-to-nearest bf16 pieces (24 significant bits: exact for every finite fp32 whose bf16 rounding does
+// not overflow), for two values at once: h / m / l hold the pieces of v0 in their low and of v1 in their high halves.
+// 3 v_cvt_pk_bf16_f32 + 4 shift / mask + 4 subtract.  (Tried, round 3: the residuals by v_dot2c_f32_bf16 with a (-1, 0) / (0, -1)
+// operand -- one instruction per element instead of two -- measured 2-3 % SLOWER in all three kernels that cut operands, and the
+// packed inline constant does not mean what the builtin's vector literal says: wrong pieces.  Not kept.)
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(v0, v1);
+    v0 -= __uint_as_float(h << 16);
+    v1 -= __uint_as_float(h & 0xFFFF0000u);
+    m = cvt_pk_bf16(v0, v1);
+    v0 -= __uint_as_float(m << 16);
+    v1 -= __uint_as_float(m & 0xFFFF0000u);
+    l = cvt_pk_bf16(v0, v1);
+}
+
 // LDS-DMA: 16 B per lane from `gptr` (per lane) to lds_base + lane*16 (lds_base wave-uniform).
 __device__ __forceinline__ void dma16(const float* gptr, float* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,

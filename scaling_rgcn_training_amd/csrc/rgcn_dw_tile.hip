@@ -174,13 +174,7 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
         l = pk(v0, v1);
         return;
 #endif
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
-        v0 -= __uint_as_float(h << 16);
-        v1 -= __uint_as_float(h & 0xFFFF0000u);
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m) : "v"(v0), "v"(v1));
-        v0 -= __uint_as_float(m << 16);
-        v1 -= __uint_as_float(m & 0xFFFF0000u);
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(v0), "v"(v1));
+        split3_pair(v0, v1, h, m, l);
     };
     // half a unit as ONE 32-row k-step (a half with no valid slot is skipped; padding slots inside one have weight 0)
     auto compute_half3 = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {

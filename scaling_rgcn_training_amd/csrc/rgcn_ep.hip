@@ -182,16 +182,11 @@ __global__ void __launch_bounds__(256) rgcn_ep_transform3_kernel(const EpArgs a)
             for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
                 for (int jp = 0; jp < 4; ++jp) {
-                    float v0 = cur[2 * sk + (jp >> 1)][2 * (jp & 1)], v1 = cur[2 * sk + (jp >> 1)][2 * (jp & 1) + 1];
-                    const unsigned h = cvt_pk_bf16(v0, v1);
-                    v0 -= __uint_as_float(h << 16);
-                    v1 -= __uint_as_float(h & 0xFFFF0000u);
-                    const unsigned m = cvt_pk_bf16(v0, v1);
-                    v0 -= __uint_as_float(m << 16);
-                    v1 -= __uint_as_float(m & 0xFFFF0000u);
+                    unsigned h, m, l;
+                    split3_pair(cur[2 * sk + (jp >> 1)][2 * (jp & 1)], cur[2 * sk + (jp >> 1)][2 * (jp & 1) + 1], h, m, l);
                     xp[0][sk][jp] = h;
                     xp[1][sk][jp] = m;
-                    xp[2][sk][jp] = cvt_pk_bf16(v0, v1);
+                    xp[2][sk][jp] = l;
                 }
             float* zr = a.z + (slot0 + 16 * t) * (size_t)a.ldz + 4 * kq;
 #pragma unroll

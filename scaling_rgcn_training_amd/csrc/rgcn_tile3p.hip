@@ -190,17 +190,8 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
                 x0 -= top(x0); x1 -= top(x1); x2 -= top(x2); x3 -= top(x3);
                 l0 = pk(x0, x1); l1 = pk(x2, x3);
             } else {
-                h0 = p3_cvt_pk_bf16(x0, x1); h1 = p3_cvt_pk_bf16(x2, x3);
-                x0 -= __uint_as_float(h0 << 16);
-                x1 -= __uint_as_float(h0 & 0xFFFF0000u);
-                x2 -= __uint_as_float(h1 << 16);
-                x3 -= __uint_as_float(h1 & 0xFFFF0000u);
-                m0 = p3_cvt_pk_bf16(x0, x1); m1 = p3_cvt_pk_bf16(x2, x3);
-                x0 -= __uint_as_float(m0 << 16);
-                x1 -= __uint_as_float(m0 & 0xFFFF0000u);
-                x2 -= __uint_as_float(m1 << 16);
-                x3 -= __uint_as_float(m1 & 0xFFFF0000u);
-                l0 = p3_cvt_pk_bf16(x0, x1); l1 = p3_cvt_pk_bf16(x2, x3);
+                split3_pair(x0, x1, h0, m0, l0);
+                split3_pair(x2, x3, h1, m1, l1);
             }
             char* p = slot + row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + ((c & 1) << 3);
             if (RGCN_P3_ABL & 32) {      // timing only: no plane stores
