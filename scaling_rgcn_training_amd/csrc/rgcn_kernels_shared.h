@@ -1,6 +1,7 @@
 // rgcn_kernels_shared.h -- what the kernel translation units of librgcn_mi355x.so share besides rgcn_common.h: the diagnostic
 // build knobs, the LDS-DMA row gather of the ring kernels, and the host-side argument checks of the C ABI.
-//   rgcn_tile_fp32.hip   forward / dX in exact fp32 (every width class) + rgcn_fwd / rgcn_bwd_dx
+//   rgcn_tile_fp32.hip   rgcn_fwd / rgcn_bwd_dx; the exact-fp32 forward / dX kernel (every width class) is rgcn_tile_fp32_kernel.h,
+//                        instantiated in rgcn_tile_fp32_narrow.hip / _wide.hip
 //   rgcn_tile3p.hip      forward / dX of 64 x 64 layers on bf16 x 3 MFMAs (the default there)
 //   rgcn_dw_relmajor.hip weight gradients, relation-major walks (every width class) + rgcn_bwd_dw
 //   rgcn_dw_tile.hip     weight gradients, tile-major walk (64 x 64, <= 32 relations) + rgcn_bwd_dw_tiles

@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 if [[ "${1:-}" == "--temps" ]]; then
   mkdir -p "$2"; cd "$2"
-  for f in rgcn_tile_fp32 rgcn_tile3p rgcn_dw_relmajor rgcn_dw_tile rgcn_dw_root rgcn_ep rgcn_abi rgcn_plan; do
+  for f in rgcn_tile_fp32 rgcn_tile_fp32_narrow rgcn_tile_fp32_wide rgcn_tile3p rgcn_dw_relmajor rgcn_dw_tile rgcn_dw_root rgcn_ep rgcn_abi rgcn_plan; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -save-temps -Rpass-analysis=kernel-resource-usage \
         "$ROOT/scaling_rgcn_training_amd/csrc/$f.hip" -o "$f.o" 2> "$f.resources.txt"
   done

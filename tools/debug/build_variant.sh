@@ -9,7 +9,7 @@ out="$ROOT/scaling_rgcn_training_amd/_build/variants"
 mkdir -p "$out/obj_$name"
 cd "$out/obj_$name"
 C="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC"
-for f in rgcn_tile_fp32 rgcn_tile3p rgcn_dw_relmajor rgcn_dw_tile rgcn_dw_root rgcn_ep rgcn_abi; do
+for f in rgcn_tile_fp32 rgcn_tile_fp32_narrow rgcn_tile_fp32_wide rgcn_tile3p rgcn_dw_relmajor rgcn_dw_tile rgcn_dw_root rgcn_ep rgcn_abi; do
   $C "$@" -c "$ROOT/scaling_rgcn_training_amd/csrc/$f.hip" -o $f.o &
 done
 $C -c "$ROOT/scaling_rgcn_training_amd/csrc/rgcn_plan.hip" -o rgcn_plan.o

@@ -8,6 +8,6 @@ B="$ROOT/scaling_rgcn_training_amd/_build"
 out="$B/variants"
 mkdir -p "$out"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c "$ROOT/scaling_rgcn_training_amd/csrc/rgcn_tile3p.hip" -o "$out/p3_$name.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$B/rgcn_tile_fp32.o" "$B/rgcn_dw_relmajor.o" "$B/rgcn_dw_tile.o" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$B/rgcn_tile_fp32.o" "$B/rgcn_tile_fp32_narrow.o" "$B/rgcn_tile_fp32_wide.o" "$B/rgcn_dw_relmajor.o" "$B/rgcn_dw_tile.o" \
     "$B/rgcn_dw_root.o" "$B/rgcn_ep.o" "$B/rgcn_abi.o" "$B/rgcn_plan.o" "$out/p3_$name.o" -o "$out/$name.so"
 echo "built $out/$name.so"

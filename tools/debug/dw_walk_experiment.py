@@ -13,7 +13,7 @@ if nt:
     if not os.path.exists(so):
         csrc = os.path.join(ROOT, "scaling_rgcn_training_amd", "csrc")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRGCN_DW_X_AUX=2"] +
-                       [os.path.join(csrc, f + ".hip") for f in ("rgcn_tile_fp32", "rgcn_tile3p", "rgcn_dw_relmajor", "rgcn_dw_tile",
+                       [os.path.join(csrc, f + ".hip") for f in ("rgcn_tile_fp32", "rgcn_tile_fp32_narrow", "rgcn_tile_fp32_wide", "rgcn_tile3p", "rgcn_dw_relmajor", "rgcn_dw_tile",
                                                                   "rgcn_dw_root", "rgcn_ep", "rgcn_abi", "rgcn_plan")] + ["-o", so], check=True)
     _lib.LIB_PATH = so
 _lib.load()

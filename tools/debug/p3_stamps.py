@@ -10,7 +10,7 @@ os.makedirs(os.path.dirname(so), exist_ok=True)
 H = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 DEFS = os.environ.get("P3_DEFS", "").split()
 subprocess.run(H + ["-DRGCN_P3_STAMPS"] + DEFS + ["-c", os.path.join(ROOT, "scaling_rgcn_training_amd/csrc/rgcn_tile3p.hip"), "-o", so + ".o"], check=True)
-subprocess.run(H + ["-shared"] + [os.path.join(B, f"rgcn_{n}.o") for n in ("tile_fp32", "dw_relmajor", "dw_tile", "dw_root", "ep", "abi", "plan")] + [so + ".o", "-o", so], check=True)
+subprocess.run(H + ["-shared"] + [os.path.join(B, f"rgcn_{n}.o") for n in ("tile_fp32", "tile_fp32_narrow", "tile_fp32_wide", "dw_relmajor", "dw_tile", "dw_root", "ep", "abi", "plan")] + [so + ".o", "-o", so], check=True)
 from scaling_rgcn_training_amd import _lib
 _lib.LIB_PATH = so
 lib = _lib.load()

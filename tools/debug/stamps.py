@@ -9,7 +9,7 @@ os.makedirs(os.path.dirname(so), exist_ok=True)
 abl = os.environ.get("RGCN_ABL", "0")
 CSRC = os.path.join(ROOT, "scaling_rgcn_training_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRGCN_STAMPS", "-DRGCN_ABL=" + abl] +
-               [os.path.join(CSRC, f + ".hip") for f in ("rgcn_tile_fp32", "rgcn_tile3p", "rgcn_dw_relmajor", "rgcn_dw_tile", "rgcn_dw_root",
+               [os.path.join(CSRC, f + ".hip") for f in ("rgcn_tile_fp32", "rgcn_tile_fp32_narrow", "rgcn_tile_fp32_wide", "rgcn_tile3p", "rgcn_dw_relmajor", "rgcn_dw_tile", "rgcn_dw_root",
                                                           "rgcn_ep", "rgcn_abi", "rgcn_plan")] + ["-o", so], check=True)
 from scaling_rgcn_training_amd import _lib
 _lib.LIB_PATH = so
