@@ -54,6 +54,15 @@ __device__ __forceinline__ unsigned long long p3_stamp() {
 #ifndef RGCN_P3_TRUNC
 #define RGCN_P3_TRUNC 0
 #endif
+// wave priorities (s_setprio 0..3) of the producer / consumer waves: issue is arbitrated by priority, then age.  The consumers are the
+// critical path of a chunk; with priority 3 their LDS and MFMA issue goes ahead of the producer wave on the same SIMD: forward launch
+// 8.87 / 8.87 ms against 9.11 / 8.96 at equal priorities, A/B on one box (producers 3: 9.05 / 9.04; producers 1 + consumers 2: 8.85)
+#ifndef RGCN_P3_PRIO_PROD
+#define RGCN_P3_PRIO_PROD 0
+#endif
+#ifndef RGCN_P3_PRIO_CONS
+#define RGCN_P3_PRIO_CONS 3
+#endif
 // 1: the consumers drain their LDS queue (s_waitcnt lgkmcnt(0)) in front of EVERY chunk barrier; 0: only where a tile closes.
 // Per-wave stamps (round 3, profiles/r03a_*) show every consumer wave waiting ~400 cycles per chunk at that barrier with the
 // producers long there -- the drain of its last accumulator stores; without it the same wait moves to the next chunk's first
@@ -310,6 +319,10 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
         out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
     }
 
+    if (RGCN_P3_PRIO_PROD != 0 || RGCN_P3_PRIO_CONS != 0) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(RGCN_P3_PRIO_CONS);
+        else __builtin_amdgcn_s_setprio(RGCN_P3_PRIO_PROD);
+    }
     if (wave >= 4) {
         // ---- consumers: wave cw = (team, column group cg) owns output columns 16 NCT cg .. + 16 NCT - 1 of its team's rows ----
         const int cw = wave - 4;
