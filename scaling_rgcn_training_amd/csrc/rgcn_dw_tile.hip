@@ -33,6 +33,12 @@ namespace rgcn {
 #ifndef RGCN_DW_VECTOR_WALK
 #define RGCN_DW_VECTOR_WALK 0
 #endif
+// wave priority raised around the MFMA block of every output-column group (1) or around its vector work (2); 0: none.  Two waves
+// share a SIMD and alternate between cutting operands and multiplying: 7.00 / 7.01 ms (1), 7.01 / 6.99 (2) against 7.08 / 7.06 (0),
+// A/B on one box -- a per cent, kept at 1
+#ifndef RGCN_DW_PRIO
+#define RGCN_DW_PRIO 1
+#endif
 #ifndef RGCN_DW_XCD_MAP
 #define RGCN_DW_XCD_MAP 1
 #endif
@@ -214,12 +220,16 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
                     asm volatile("" ::"v"(ap[0][ia]), "v"(ap[1][ia]), "v"(ap[2][ia]), "v"(bp[0]), "v"(bp[1]), "v"(bp[2]));
                 continue;
             }
+            if (RGCN_DW_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+            if (RGCN_DW_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
                 for (int ia = 0; ia < 4; ++ia)
                     acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[pa[q]][ia]),
                                                                           __builtin_bit_cast(bf16x8, bp[pb[q]]), acc[ia][jb], 0, 0, 0);
+            if (RGCN_DW_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (RGCN_DW_PRIO == 2) __builtin_amdgcn_s_setprio(3);
         }
     };
 
