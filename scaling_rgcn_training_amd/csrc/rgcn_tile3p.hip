@@ -63,6 +63,11 @@ __device__ __forceinline__ unsigned long long p3_stamp() {
 #ifndef RGCN_P3_PRIO_CONS
 #define RGCN_P3_PRIO_CONS 3
 #endif
+// which waves are consumers: 0 = waves 4 .. (one producer and one consumer per SIMD with the one-team kernel: wave i runs on SIMD i % 4);
+// 1 (one-team kernel only) = waves 0, 1, 4, 5 -- the consumers two per SIMD on SIMDs 0 / 1, the producers on SIMDs 2 / 3
+#ifndef RGCN_P3_ROLEMAP
+#define RGCN_P3_ROLEMAP 0
+#endif
 // 1: the consumers drain their LDS queue (s_waitcnt lgkmcnt(0)) in front of EVERY chunk barrier; 0: only where a tile closes.
 // Per-wave stamps (round 3, profiles/r03a_*) show every consumer wave waiting ~400 cycles per chunk at that barrier with the
 // producers long there -- the drain of its last accumulator stores; without it the same wait moves to the next chunk's first
@@ -319,13 +324,16 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
         out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
     }
 
+    constexpr bool kRoleMap = RGCN_P3_ROLEMAP && kConsumers == 4;
+    const bool is_consumer = kRoleMap ? (wave & 2) == 0 : wave >= 4;
+    const int role_idx = kRoleMap ? ((wave >> 2) * 2 + (wave & 1)) : (wave >= 4 ? wave - 4 : wave);       // cw or pw
     if (RGCN_P3_PRIO_PROD != 0 || RGCN_P3_PRIO_CONS != 0) {
-        if (wave >= 4) __builtin_amdgcn_s_setprio(RGCN_P3_PRIO_CONS);
+        if (is_consumer) __builtin_amdgcn_s_setprio(RGCN_P3_PRIO_CONS);
         else __builtin_amdgcn_s_setprio(RGCN_P3_PRIO_PROD);
     }
-    if (wave >= 4) {
+    if (is_consumer) {
         // ---- consumers: wave cw = (team, column group cg) owns output columns 16 NCT cg .. + 16 NCT - 1 of its team's rows ----
-        const int cw = wave - 4;
+        const int cw = role_idx;
         const int team = cw / CG, cg = cw % CG;
         const int rowl = lane & 15, kq = lane >> 4;
         const unsigned col4_bytes = (unsigned)(16 * NCT * cg + 4 * kq) * 4u;     // Y^T layout: four consecutive columns of row rowl
@@ -591,7 +599,7 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
             if (it + 1 == tend && it + 1 < nch) {
                 // this chunk closed a tile: the consumer threads store it and reset the accumulator; the producers wait at
                 // the same extra barrier with the next tile's first chunks already in LDS / in flight
-                tile_epilogue<LDO, true>(a, out_lds, tile_cur, tid - 256, 64 * kConsumers);
+                tile_epilogue<LDO, true>(a, out_lds, tile_cur, cw * 64 + lane, 64 * kConsumers);
                 ++tile_cur;
                 tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the epilogue's memory operations here, once per tile
@@ -608,7 +616,7 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
 #endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the consumers is pending when the producer code follows
     }
-    if (wave < 4) p3_producer_loop(a, ring, wring, dring, c0, nch, lane, wave, tile0);
+    if (!is_consumer) p3_producer_loop(a, ring, wring, dring, c0, nch, lane, role_idx, tile0);
     tile_epilogue<LDO, false>(a, out_lds, tile1 - 1, tid, kThreadsAll);
 }
 
