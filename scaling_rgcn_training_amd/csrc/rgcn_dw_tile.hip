@@ -35,12 +35,34 @@ namespace rgcn {
 #endif
 // wave priority raised around the MFMA block of every output-column group (1) or around its vector work (2); 0: none.  Two waves
 // share a SIMD and alternate between cutting operands and multiplying: 7.00 / 7.01 ms (1), 7.01 / 6.99 (2) against 7.08 / 7.06 (0),
-// A/B on one box -- a per cent, kept at 1
+// A/B on one box -- a per cent, kept at 1.  (The two waves of a SIMD at DIFFERENT priorities for the whole launch, so that they
+// fall out of step: 7.0-7.1 ms against 6.76, worse in all three forms tried.)
 #ifndef RGCN_DW_PRIO
 #define RGCN_DW_PRIO 1
 #endif
+#ifndef RGCN_DW_PIPE
+#define RGCN_DW_PIPE 3     // vector instructions issued behind every MFMA of the split form (0: phases, the round-2 form)
+#endif
+#ifndef RGCN_DW_STAGED
+#define RGCN_DW_STAGED 1   // the A pieces cut four pairs at a time, stage by stage
+#endif
 #ifndef RGCN_DW_XCD_MAP
 #define RGCN_DW_XCD_MAP 1
+#endif
+// Diagnostic build only (-DRGCN_DW_STAMPS, tools/debug/dw_stamps.py): per-phase cycle sums of every wave of the split form,
+// written to a buffer no other code reads.  A stamp is s_memtime + lgkmcnt(0): it also waits for the LDS operations in flight.
+#ifdef RGCN_DW_STAMPS
+__device__ unsigned long long* g_dw_stamps = nullptr;
+__device__ __forceinline__ unsigned dw_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return (unsigned)t;
+}
+#define DWS(i) { const unsigned now_ = dw_stamp(); ph[i] += now_ - last_; last_ = now_; }
+#else
+#define DWS(i)
 #endif
 constexpr int kDwTileT = 304;                    // gradient rows per LDS buffer = tile size of the plan this kernel walks
 constexpr int kDwTileWalkers = 64;               // tile ranges; x 4 relation quarters = 256 workgroups, one per CU
@@ -99,6 +121,10 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     for (int ia = 0; ia < 4; ++ia)
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) acc[ia][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef RGCN_DW_STAMPS
+    unsigned ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned last_ = dw_stamp();
+#endif
 
     // tile t -> LDS buffer b: DMA instruction i moves rows 4 i .. 4 i + 3 (64 lanes x 16 bytes); rows past the end read zeros
     auto dma_tile = [&](int t, int b) {
@@ -195,7 +221,35 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             const int o = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), goff);
             g4[s] = *(const f32x4*)((const char*)gbuf + o + colb);
         }
+        DWS(2 + 5 * h)       // weights and gradient rows of the half out of LDS
         u32x4 ap[3][4];      // [piece][ia]: 8 bf16 = k index 8 kq + 0..7 of input channel 4 ml + ia
+#if RGCN_DW_STAGED
+        // the four pairs of an input channel cut side by side, stage by stage (split3_pair's arithmetic, same pieces): left
+        // alone the scheduler emits one dependent chain after the other with a wait state behind every conversion
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia) {
+            float v0[4], v1[4];
+            unsigned pc[4];
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) { v0[jp] = a4[2 * jp][ia]; v1[jp] = a4[2 * jp + 1][ia]; }
+#pragma unroll
+            for (int piece = 0; piece < 3; ++piece) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) pc[jp] = cvt_pk_bf16(v0[jp], v1[jp]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) ap[piece][ia][jp] = pc[jp];
+                if (piece < 2) {
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        v0[jp] -= __uint_as_float(pc[jp] << 16);
+                        v1[jp] -= __uint_as_float(pc[jp] & 0xFFFF0000u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int ia = 0; ia < 4; ++ia)
 #pragma unroll
@@ -204,7 +258,79 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
                 split_pair(a4[2 * jp][ia], a4[2 * jp + 1][ia], h_, m_, l_);
                 ap[0][ia][jp] = h_; ap[1][ia][jp] = m_; ap[2][ia][jp] = l_;
             }
+#endif
+        DWS(3 + 5 * h)       // the x rows have arrived and are cut
         constexpr int pa[6] = {2, 1, 1, 0, 0, 0}, pb[6] = {0, 1, 0, 2, 1, 0};      // small products first
+#if RGCN_DW_PIPE
+        // Software pipeline over the four output-column groups: the B pieces of group jb + 1 are cut in the shadow of group jb's
+        // 24 MFMAs.  A 16x16x32 bf16 MFMA holds the matrix pipe for 16 cycles = four issue slots, of which it takes one: the
+        // other three go to the SAME wave's vector instructions (the second wave of the SIMD does not fill them: its vector
+        // phase and this wave's MFMA phase ran one after the other, MFMA time came on top of everything else -- DESIGN.md 4.3).
+        // The order is forced with sched_group_barrier (one MFMA, then up to RGCN_DW_PIPE vector instructions, 24 times);
+        // left alone the scheduler keeps runs of 24 MFMAs.
+        auto cut_b = [&](int jb, u32x4 (&bp)[3]) {
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                unsigned h_, m_, l_;
+                if (RGCN_DW_ABL & 8) {      // (timing only: the B side without its cut -- what pieces staged per tile could save at most)
+                    h_ = __float_as_uint(g4[2 * jp][jb]); m_ = __float_as_uint(g4[2 * jp + 1][jb]); l_ = __float_as_uint(wv[2 * jp]) ^ __float_as_uint(wv[2 * jp + 1]);
+                } else
+                split_pair(g4[2 * jp][jb] * wv[2 * jp], g4[2 * jp + 1][jb] * wv[2 * jp + 1], h_, m_, l_);
+                bp[0][jp] = h_; bp[1][jp] = m_; bp[2][jp] = l_;
+            }
+        };
+        u32x4 bpp[2][3];
+#if RGCN_DW_STAGED
+        {      // group 0 is cut in the open: staged like the A pieces
+            float v0[4], v1[4];
+            unsigned pc[4];
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) { v0[jp] = g4[2 * jp][0] * wv[2 * jp]; v1[jp] = g4[2 * jp + 1][0] * wv[2 * jp + 1]; }
+#pragma unroll
+            for (int piece = 0; piece < 3; ++piece) {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) pc[jp] = cvt_pk_bf16(v0[jp], v1[jp]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) bpp[0][piece][jp] = pc[jp];
+                if (piece < 2) {
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        v0[jp] -= __uint_as_float(pc[jp] << 16);
+                        v1[jp] -= __uint_as_float(pc[jp] & 0xFFFF0000u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#else
+        cut_b(0, bpp[0]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        DWS(4 + 5 * h)       // column group 0 of B cut
+        if (RGCN_DW_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            if (jb < 3) cut_b(jb + 1, bpp[(jb + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int ia = 0; ia < 4; ++ia)
+                    acc[ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ap[pa[q]][ia]),
+                                                                          __builtin_bit_cast(bf16x8, bpp[jb & 1][pb[q]]), acc[ia][jb], 0, 0, 0);
+            if (jb < 3) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, RGCN_DW_PIPE, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (RGCN_DW_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        DWS(5 + 5 * h)       // 96 MFMAs issued, the cuts of groups 1-3 between them
+        return;
+#endif
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
             u32x4 bp[3];
@@ -263,21 +389,27 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
         // prologue's loads), more than kInFlight younger operations exist and at most kInFlight are in flight at a unit boundary (8 row
         // loads + 3 index loads of the unit after next + the walk words): a counted wait retires the DMAs and leaves the prefetches alone.  A wave
         // without units in between (an empty relation) has nothing younger to count: it waits for everything.
+        DWS(12)
         if (walked) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DWS(13)              // the tile's DMAs
 #if !RGCN_DW_ABL_NOBARRIER      // (timing only: the waves of a workgroup run free -- what the tile lockstep costs)
         wg_barrier();          // tile t landed for every wave; every wave is done with the buffer tile t + 1 goes to
 #endif
+        DWS(14)              // the barrier
         const int b = (t - t0) & 1;
         if (t + 1 < t1) dma_tile(t + 1, b ^ 1);
         walked = false;
+        DWS(15)              // next tile's DMAs issued
         const float* gbuf = lds + b * T * NP;
         while (k < nun && tile_cur == t) {
             const int ngrp = (cnt_cur + 15) >> 4, nks = (cnt_cur + 3) >> 2;
             walked = true;
+            DWS(0)               // (loop overhead, walk words)
             issue_half(s1, ix_cur, 1);
             pin_loads();
             __builtin_amdgcn_sched_barrier(0);
+            DWS(1)               // second half's rows issued
             if constexpr (SPLIT) compute_half3(s0, ix_cur, 0, ngrp, gbuf, t * T);
             else compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
@@ -285,6 +417,7 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             issue_half(s0, ix_nxt, 0);
             pin_loads();
             __builtin_amdgcn_sched_barrier(0);
+            DWS(6)               // next unit's indices and first-half rows issued
             if constexpr (SPLIT) compute_half3(s1, ix_cur, 1, ngrp, gbuf, t * T);
             else compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
@@ -308,6 +441,11 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
 #endif
         }
     }
+#ifdef RGCN_DW_STAMPS
+    ph[11] = (unsigned)k;
+    if (g_dw_stamps && lane == 0)
+        for (int i = 0; i < 16; ++i) g_dw_stamps[((size_t)blockIdx.x * 8 + wave) * 16 + i] = ph[i];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the accumulators are read by plain stores the compiler schedules: keep them clear of the last asm MFMA
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -358,6 +496,12 @@ __global__ void rgcn_dw_tile_reduce_kernel(const float* __restrict__ slabs, int 
 }  // namespace rgcn
 
 using namespace rgcn;
+
+#ifdef RGCN_DW_STAMPS
+extern "C" int rgcn_debug_set_dw_stamps(unsigned long long* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_stamps), &p, sizeof(p));
+}
+#endif
 
 extern "C" int rgcn_dw_tiles_geometry(int* tile, int* walkers, int* max_relations) {
     if (tile) *tile = kDwTileT;
