@@ -51,6 +51,17 @@ __global__ void __launch_bounds__(512) probe(long long* cyc, int iters, float* s
                 if (KIND == 3) VCVT(u[r], f[r], f[(r + 1) & 7]);
                 if (KIND == 4) VLSH(u[r], u[(r + 3) & 7]);
                 if (KIND == 5) VAND(u[r], u[(r + 3) & 7]);
+                if (KIND == 7) asm volatile("v_mul_u32_u24 %0, 0x10000, %1" : "=v"(u[r]) : "v"(u[(r + 3) & 7]));
+                if (KIND == 8) asm volatile("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(u[r]) : "v"(u[(r + 3) & 7]), "v"(u[(r + 5) & 7]));
+                if (KIND == 9) asm volatile("v_alignbit_b32 %0, %1, 0, 16" : "=v"(u[r]) : "v"(u[(r + 3) & 7]));
+                if (KIND == 10) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(f[r]) : "v"(f[(r + 3) & 7]), "v"(f[(r + 5) & 7]));
+                if (KIND == 11) asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(u[r]) : "v"(u[(r + 3) & 7]));
+                if (KIND == 12) asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(u[r]) : "v"(u[(r + 3) & 7]), "v"(sel), "v"(u[(r + 5) & 7]));
+                if (KIND == 13) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(u[r]) : "v"(sel), "v"(u[(r + 3) & 7]), "v"(u[(r + 5) & 7]));
+                if (KIND == 14) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(u[r]) : "v"(u[(r + 3) & 7]));
+                if (KIND == 15) asm volatile("v_lshlrev_b32_e64 %0, 16, %1" : "=v"(u[r]) : "v"(u[(r + 3) & 7]));
+                if (KIND == 16) asm volatile("v_lshlrev_b32 %0, %1, %2" : "=v"(u[r]) : "v"(sel), "v"(u[(r + 3) & 7]));
+                if (KIND == 17) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(f[r]) : "v"(f[(r + 3) & 7]), "v"(f[(r + 5) & 7]));
                 if (KIND == 6) VPKADD(p2[r & 3], p2[(r + 1) & 3], p2[(r + 2) & 3]);
             }
         }
@@ -65,7 +76,7 @@ __global__ void __launch_bounds__(512) probe(long long* cyc, int iters, float* s
 template <int K, int KIND, bool MF>
 static void run(long long* d, float* sink) {
     const int iters = 4000;
-    static const char* kinds[] = {"v_fma_f32", "cvt_pk / shift / and / fma", "v_perm_b32", "v_cvt_pk_bf16_f32", "v_lshlrev_b32", "v_and_b32", "v_pk_add_f32"};
+    static const char* kinds[] = {"v_fma_f32", "cvt_pk / shift / and / fma", "v_perm_b32", "v_cvt_pk_bf16_f32", "v_lshlrev_b32", "v_and_b32", "v_pk_add_f32", "v_mul_u32_u24", "v_lshl_add_u32", "v_alignbit_b32", "v_sub_f32", "v_lshrrev_b32", "v_and_or_b32", "v_bfi_b32", "v_mov_b32_sdwa WORD_0 -> WORD_1", "v_lshlrev_b32_e64", "v_lshlrev_b32 (register shift)", "v_mul_f32"};
     for (int threads = 256; threads <= 512; threads += 256) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -97,5 +108,8 @@ int main() {
     run<3, 2, true>(d, sink); run<3, 2, false>(d, sink);
     run<6, 3, false>(d, sink); run<6, 4, false>(d, sink); run<6, 5, false>(d, sink); run<6, 6, false>(d, sink);
     run<3, 3, true>(d, sink); run<3, 6, true>(d, sink);
+    run<6, 7, false>(d, sink); run<6, 8, false>(d, sink); run<6, 9, false>(d, sink); run<6, 10, false>(d, sink); run<6, 11, false>(d, sink);
+    run<6, 12, false>(d, sink); run<6, 13, false>(d, sink);
+    run<6, 14, false>(d, sink); run<6, 15, false>(d, sink); run<6, 16, false>(d, sink); run<6, 17, false>(d, sink);
     return 0;
 }
