@@ -61,3 +61,47 @@ def test_current_reference_semantics_lowercase_and_type_excluded(tmp_path):
     g = G.Graph("sum")
     g.init_graph(G.parse_graph_nt(os.path.join(sum_dir, "T_sum_in_out.nt")))
     assert g.training_data.edge_index.shape[0] == 2 and g.num_nodes >= 2
+
+
+def test_murmur3_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The host C code built with -fsanitize=address,undefined (CPU build only: no GPU sanitizer on this pool) and run over
+    every tail length on exactly-sized heap buffers at odd offsets: an over-read by one byte or a misaligned wide load aborts
+    the child.  Its digests must equal the product library's."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = os.path.join(os.path.dirname(S.HOST_LIB_PATH), "csrc", "murmur3_x64_128.c")
+    main = tmp_path / "main.c"
+    main.write_text(r'''
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+void rgcn_murmur3_x64_128(const void* key, int64_t len, uint32_t seed, uint64_t out[2]);
+int main(void) {
+    for (int n = 0; n < 70; ++n)
+        for (int off = 0; off < 3; ++off) {
+            unsigned char* base = (unsigned char*)malloc((size_t)n + off + (n + off == 0));
+            for (int i = 0; i < n; ++i) base[off + i] = (unsigned char)(i * 7 + 3);
+            uint64_t out[2];
+            rgcn_murmur3_x64_128(base + off, n, (uint32_t)off, out);
+            printf("%d %d %016llx %016llx\n", n, off, (unsigned long long)out[0], (unsigned long long)out[1]);
+            free(base);
+        }
+    return 0;
+}
+''')
+    exe = tmp_path / "murmur_asan"
+    subprocess.run([gcc, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", str(main), src, "-o", str(exe)],
+                   check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = res.stdout.split("\n")[:-1]
+    assert len(lines) == 70 * 3
+    for ln in lines:
+        n, off, h1, h2 = ln.split()
+        n, off = int(n), int(off)
+        want = S.hash128(bytes((i * 7 + 3) & 255 for i in range(n)), seed=off)
+        assert want == (int(h2, 16) << 64) | int(h1, 16), (n, off)
