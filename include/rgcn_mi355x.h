@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 14
+#define RGCN_ABI_VERSION 15
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -87,14 +87,22 @@ typedef struct rgcn_plan {
                             * ceil(nt / 2) row tiles and part B on the others, so the two parts scatter into disjoint rows
                             * (chunk_flags bit 8: they do not) and experiment builds of the forward / dX kernel of 64 x 64 layers give
                             * each part to its own team of consumer waves; same chunks and row-tile counts as layout 0;
-                            * 2: no tiles -- dense relation-major units for rgcn_bwd_dw only (rgcn_edge_units) */
+                            * 2: no tiles -- dense relation-major units for rgcn_bwd_dw only (rgcn_edge_units);
+                            * 3 (chunk = 128): layout 0 with the rows of a (destination, relation) run on ONE slot where a chunk is
+                            * a whole (tile, relation) group with runs of at most 3 rows: heads on slots 0 .. H-1, second rows on
+                            * row tile 7 - h / 16 (place h % 16), third rows on row tile 5; chunk_cnt counts the head row tiles,
+                            * chunk_flags bits 16-17 / 18 the row tiles of second / third rows, bit 19 "the rows of a run differ in
+                            * weight" (a shadow slot's slot_acc then holds the float weight / head's weight).  Walked by rgcn_fwd / rgcn_bwd_dx with RGCN_FLAG_SPLIT_PRODUCERS on 64 x 64 layers only (the
+                            * producer waves add a run's rows before they cut them: aggregate, then transform); every other
+                            * entry point answers RGCN_ERR_PLAN */
     int32_t reserved;
     const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
     const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */
     const int32_t* chunk_cnt;  /* [n_chunks] slots of the chunk's used 16-slot MFMA row tiles (16, 32, ... chunk);
                                 * padding slots sit at the end of every row tile */
     const int32_t* chunk_tile; /* [n_chunks] */
-    const int32_t* chunk_flags; /* [n_chunks] bit t: row tile t holds a repeated destination (needs the run-sum) */
+    const int32_t* chunk_flags; /* [n_chunks] bit t: row tile t holds a repeated destination (needs the run-sum); layout 1: bit 8;
+                                 * layout 3: bits 16-19, see `layout` */
     const int32_t* rel_order;  /* [n_units] the weight-gradient walk: non-empty 64-slot units (unit u = slots
                                 * [64 u, 64 u + 64), chunk u / (chunk / 64)) sorted by (relation, tile) */
     const int32_t* slot_src;   /* [n_chunks * chunk] row to gather; padding = n_nodes (one past the last row) */
@@ -151,7 +159,7 @@ int rgcn_edge_weights(const rgcn_graph_t* graph, int aggr_sum, float* w, void* w
  * _begin sorts, merges duplicate triples and sizes the plan (SYNCHRONISES the stream: the sizes are data-dependent);
  * the caller then allocates the ten device arrays of `plan` (sizes above; nothing in this library allocates) and
  * _finish fills them and the scalar fields, asynchronously on `stream`.  tile: output nodes per tile (multiple of
- * 16), chunk: 64 or 128, layout: 0 or (chunk = 128) 1, see struct rgcn_plan.  Replaces scaling_rgcn_training_amd/plan.py (torch tensor ops), which stays as the test
+ * 16), chunk: 64 or 128, layout: 0, 2 (chunk = 64) or (chunk = 128) 1 / 3, see struct rgcn_plan.  Replaces scaling_rgcn_training_amd/plan.py (torch tensor ops), which stays as the test
  * oracle: all arrays are bit-identical. */
 int rgcn_plan_build_begin(const rgcn_graph_t* graph, const float* w, int transposed, int32_t node_begin, int32_t node_end,
                           int32_t tile, int32_t chunk, int32_t layout, void* workspace, size_t workspace_bytes,

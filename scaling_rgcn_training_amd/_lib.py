@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
@@ -27,6 +27,7 @@ EXPORTS = (
 
 # enum rgcn_act / RGCN_FLAG_* of include/rgcn_mi355x.h
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ERR_PLAN = -4          # inconsistent plan, or a plan layout the called kernel does not walk
 ERR_ADDRESS = -10      # rgcn_bwd_dw_tiles: operands not addressable through a buffer descriptor
 FLAG_POINTER_GATHER, FLAG_DW_RING, FLAG_DW_DIRECT, FLAG_EXACT_FP32, FLAG_DW_ROOT_ONLY, FLAG_SPLIT_PRODUCERS = 1, 2, 4, 8, 16, 32
 

@@ -45,6 +45,7 @@ _SPLIT_PRODUCERS_DEFAULT = os.environ.get("RGCN_SPLIT_PRODUCERS", "1")
 # "1": plans of those layers in the TEAM placement (plan layout 1, plan.team_placement) for experiment builds of the kernel
 # with two teams of consumer waves (csrc/rgcn_tile3p.hip RGCN_P3_TEAMS=2: measured no faster).  Default: layout 0
 _TEAM_LAYOUT_DEFAULT = os.environ.get("RGCN_TEAM_LAYOUT", "0") == "1"
+_MERGE_RUNS_DEFAULT = os.environ.get("RGCN_MERGE_RUNS", "1") == "1"
 _PATH_DEFAULT = os.environ.get("RGCN_PATH", "auto")       # auto | ring | ep
 SPLIT_PRODUCERS_TILE = 224       # the largest tile whose fp32 accumulator fits beside the kernel's two 48 KiB ring slots
 DW_TILES_MIN_EDGES = 4_000_000
@@ -254,7 +255,8 @@ class _RGCNLayerFn(torch.autograd.Function):
         # with a tenth of a launch's MFMAs, uses no LDS and few registers, so its workgroups share the CUs with the MFMA-bound
         # dX kernel instead of adding their ~1 ms behind it.  The join is a stream wait, never a host sync.
         dwp = getattr(plans, "dw", None) if dctx is None else None
-        tiles_path = (dwp is not None and need_w and plans.fwd is not None and plans.fwd.n_owned > 0 and
+        merged = plans.fwd is not None and getattr(plans.fwd, "layout", 0) == 3 if dctx is None else False
+        tiles_path = (dwp is not None and (need_w or merged) and plans.fwd is not None and plans.fwd.n_owned > 0 and
                       not (flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)) and
                       _lib.buffer_addressable(n, xp.shape[1]) and _lib.buffer_addressable(n, gp.shape[1]))
         tiles_part = side = None
@@ -290,7 +292,8 @@ class _RGCNLayerFn(torch.autograd.Function):
             dx = dxp if ldx == din else dxp[:, :din]
         if tiles_path:
             # relations: tile-major kernel (gradient rows staged in LDS)
-            _lib.bwd_dw_tiles(_lib.plan_struct(dwp), plans.dw_walk, xp, din, gp, dout, views(tiles_part)[0], flags)
+            if need_w:
+                _lib.bwd_dw_tiles(_lib.plan_struct(dwp), plans.dw_walk, xp, din, gp, dout, views(tiles_part)[0], flags)
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)
             dw, droot, dbias = views(tiles_part)
@@ -306,10 +309,11 @@ class _RGCNLayerFn(torch.autograd.Function):
                 part = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
                 pw, pr, pb = views(part)
                 b, e = fp.node_begin, fp.node_end
-                if (dctx is not None and need_w and getattr(pc, "dw", None) is not None and not pinned
+                if (dctx is not None and (need_w or getattr(fp, "layout", 0) == 3) and getattr(pc, "dw", None) is not None and not pinned
                         and _lib.buffer_addressable(n, xp.shape[1]) and _lib.buffer_addressable(e - b, gp.shape[1])):
                     # a rank's piece on the tile-major kernel, as the single-GPU step (its root part: the piece's own rows)
-                    _lib.bwd_dw_tiles(_lib.plan_struct(pc.dw), pc.dw_walk, xp, din, gp[b:e], dout, pw, flags)
+                    if need_w:
+                        _lib.bwd_dw_tiles(_lib.plan_struct(pc.dw), pc.dw_walk, xp, din, gp[b:e], dout, pw, flags)
                     if need_root or need_bias:
                         _lib.bwd_dw_root(xp[b:e], din, gp[b:e], dout, pr, pb)
                     dctx.stats["dw_tiles_pieces"] = dctx.stats.get("dw_tiles_pieces", 0) + 1
@@ -411,6 +415,10 @@ class RGCNConv(nn.Module):
         # (forward, dX) pair pins it.  RGCN_PATH in the environment at import time sets the default.
         self.path = _PATH_DEFAULT
         self.team_layout = _TEAM_LAYOUT_DEFAULT     # plans of such layers in the team placement (experiment builds: two consumer teams)
+        # forward / dX plans in layout 3 where the producer-split kernel runs them and the tile-major kernel takes d_weight: the rows
+        # of a (destination, relation) run on ONE slot, summed by the producers before the cut -- aggregate, then transform, as the
+        # reference does; 13 % fewer row tiles at the headline config (plan.compact_runs).  RGCN_MERGE_RUNS=0 / False: layout 0
+        self.merge_runs = _MERGE_RUNS_DEFAULT
         if num_bases is not None:
             self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
             self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
@@ -473,6 +481,10 @@ class RGCNConv(nn.Module):
                     and self.num_relations <= 32 and e >= DW_TILES_MIN_EDGES and x.is_cuda
                     and _lib.buffer_addressable(n, _round4(self.in_channels))
                     and _lib.buffer_addressable(n, _round4(self.out_channels)))
+        # layout 3 only where nothing but rgcn_tile3p_kernel walks the forward / transposed plans: the split kernels unpinned
+        # (no kernel flags), d_weight on its own tile-major plan, d_root / d_bias on the plan-free streaming kernel
+        if (not split and self.merge_runs and dw_tiles and self.kernel_flags == 0 and self._use_split_producers(chunk)):
+            split = 3
         if self.dist is None:
             paths = self.path if self.path == "auto" else ((self.path, self.path) if isinstance(self.path, str) else tuple(self.path))
             if not x.is_cuda:

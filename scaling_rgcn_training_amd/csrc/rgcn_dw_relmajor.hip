@@ -868,6 +868,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
                            float* d_bias, unsigned flags, void* stream) {
     int st = check_plan(plan);
     if (st != RGCN_OK) return st;
+    if (plan->layout == 3) return RGCN_ERR_PLAN;       // (shadow slots: only the forward / dX kernel knows them)
     if (!x || !g || !workspace) return RGCN_ERR_NULL;
     if ((st = check_stride(ldx, din)) != RGCN_OK) return st;
     if ((st = check_stride(ldg, dout)) != RGCN_OK) return st;

@@ -490,6 +490,96 @@ __global__ void row_tile_kernel(const u32* dstl, u32 n_row_tiles, u32 chunk, u32
     if (dup) atomicOr((int*)&chunk_flags[c], 1 << (rt % per));
 }
 
+// Layout 3 = layout 0 + this pass (plan.compact_runs is its twin).  The rows of a (destination, relation) run all go through the same
+// W_r into the same output row: sum_k w_k x[src_k] W = (sum_k w_k x[src_k]) W -- the producers of rgcn_tile3p_kernel add the run's
+// rows in fp32 BEFORE they cut them (aggregate, then transform: the reference's own order) and the run takes ONE slot.  Chunk-local
+// and only where it is simple: chunks that are a whole (tile, relation) group, runs of at most 3 rows, at most 32 runs of 2+ rows
+// and 16 of 3; anything else keeps its layout-0 slots (always correct: the kernel reads the shadow counts per chunk).  New chunk:
+// heads (first row of every run; runs of 3 first, then of 2, then single rows, each class in destination order) on slots 0 .. H-1;
+// the second row of head h on row tile 7 - h / 16, place h % 16; the third on row tile 5, place h -- the SAME lane of the same
+// producer wave holds a head and its shadows, one row tile register apart.  chunk_cnt = 16 ceil(H / 16); chunk_flags bits 16-17 =
+// row tiles with second rows, bit 18 = a row tile with third rows, bit 19 = some run's rows differ in weight (the transposed
+// plan: 1 / c of each edge's own destination): the producers then scale a shadow row by (its weight / its head's weight) -- the
+// float in the shadow slot's slot_acc -- before they add it, and the consumers apply the head's weight as ever.  Every slot
+// keeps its own weight and its run's row (a walk over all slots with a weight -- tests/plan_emulator.py -- still sums the layer).
+__global__ void compact_runs_kernel(u32 n_chunks, u32 n_nodes, u32 tile, u32 n_own, const int32_t* __restrict__ chunk_rel,
+                                    const int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_cnt,
+                                    int32_t* __restrict__ chunk_flags, int32_t* __restrict__ slot_src, float* __restrict__ slot_w,
+                                    int32_t* __restrict__ slot_row, int32_t* __restrict__ slot_acc) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int32_t rel = chunk_rel[c], t = chunk_tile[c];
+    if (c > 0 && chunk_rel[c - 1] == rel && chunk_tile[c - 1] == t) return;
+    if (c + 1 < n_chunks && chunk_rel[c + 1] == rel && chunk_tile[c + 1] == t) return;
+    const u32 nt = (u32)chunk_cnt[c] / 16u;
+    if (nt == 0) return;
+    const size_t base = (size_t)c * 128u;
+    int32_t lsrc[128], ld[128];
+    u32 lw[128];
+    u32 n = 0;
+    const u32 tbase = (u32)t * tile;
+    for (u32 j = 0; j < nt * 16u; ++j) {
+        const size_t sl = base + (size_t)(j % nt) * 16u + j / nt;
+        const int32_t sv = slot_src[sl];
+        if ((u32)sv == n_nodes) break;
+        lsrc[n] = sv;
+        ld[n] = slot_row[sl] - (int32_t)tbase;
+        lw[n] = __float_as_uint(slot_w[sl]);
+        ++n;
+    }
+    // runs
+    u32 n1 = 0, n2 = 0, n3 = 0, uneq = 0;
+    for (u32 j = 0; j < n;) {
+        u32 len = 1;
+        while (j + len < n && ld[j + len] == ld[j]) {
+            if (lw[j + len] != lw[j]) uneq = 1u;
+            ++len;
+        }
+        if (len > 3) return;
+        if (len == 1) ++n1; else if (len == 2) ++n2; else ++n3;
+        j += len;
+    }
+    if (n2 + n3 == 0 || n3 > 16u || n2 + n3 > 32u) return;
+    const u32 H = n1 + n2 + n3, nh = (H + 15u) / 16u, ns1 = (n2 + n3 + 15u) / 16u, ns2 = n3 > 0 ? 1u : 0u;
+    if (nh >= nt || nh > (ns2 ? 5u : 8u - ns1)) return;
+    // clear the chunk, then write heads and shadows
+    for (u32 i = 0; i < 128u; ++i) {
+        slot_src[base + i] = (int32_t)n_nodes;
+        slot_w[base + i] = 0.f;
+        slot_row[base + i] = (int32_t)n_own;
+        slot_acc[base + i] = (int32_t)((15u << 24) | tile);
+    }
+    u32 h3 = 0, h2 = n3, h1 = n3 + n2;
+    for (u32 j = 0; j < n;) {
+        u32 len = 1;
+        while (j + len < n && ld[j + len] == ld[j]) ++len;
+        const u32 h = len == 3 ? h3++ : (len == 2 ? h2++ : h1++);
+        const int32_t row = (int32_t)(tbase + (u32)ld[j]);
+        slot_src[base + h] = lsrc[j];
+        slot_w[base + h] = __uint_as_float(lw[j]);
+        slot_row[base + h] = row;
+        // distinct destinations inside a head tile: the run ends where it starts; padding behind the last head keeps (15, tile)
+        slot_acc[base + h] = (int32_t)(((h & 15u) << 24) | (u32)ld[j]);
+        if (len >= 2) {
+            const size_t s1 = base + (size_t)(7u - h / 16u) * 16u + (h & 15u);
+            slot_src[s1] = lsrc[j + 1];
+            slot_w[s1] = __uint_as_float(lw[j + 1]);
+            slot_row[s1] = row;
+            slot_acc[s1] = (int32_t)__float_as_uint(__fdiv_rn(__uint_as_float(lw[j + 1]), __uint_as_float(lw[j])));
+        }
+        if (len == 3) {
+            const size_t s2 = base + 5u * 16u + h;
+            slot_src[s2] = lsrc[j + 2];
+            slot_w[s2] = __uint_as_float(lw[j + 2]);
+            slot_row[s2] = row;
+            slot_acc[s2] = (int32_t)__float_as_uint(__fdiv_rn(__uint_as_float(lw[j + 2]), __uint_as_float(lw[j])));
+        }
+        j += len;
+    }
+    chunk_cnt[c] = (int32_t)(nh * 16u);
+    chunk_flags[c] = (int32_t)((ns1 << 16) | (ns2 << 18) | (uneq << 19));
+}
+
 __global__ void tile_ptr_kernel(const int32_t* __restrict__ chunk_tile, u32 n_chunks, u32 n_tiles, int32_t* __restrict__ tile_ptr) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
@@ -695,7 +785,7 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
         tile = ((node_end - node_begin + 15) / 16) * 16;
     }
     if (tile <= 0 || (tile % 16) != 0 || (tile > 32768 && layout != 2) || (chunk != 64 && chunk != 128)) return RGCN_ERR_PLAN;
-    if (layout != 0 && layout != 2 && !(layout == 1 && chunk == 128)) return RGCN_ERR_PLAN;
+    if (layout != 0 && layout != 2 && !((layout == 1 || layout == 3) && chunk == 128)) return RGCN_ERR_PLAN;
     // (node_begin need not be a tile multiple: tiles count from node_begin.  Callers that want a rank's tiles to BE the
     // single-rank tiles -- bit-identical outputs -- align their ranges themselves: scaling_rgcn_training_amd/dist.py)
     if (node_begin < 0 || node_end <= node_begin || node_end > g->num_nodes) return RGCN_ERR_PLAN;
@@ -796,7 +886,8 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     u32* dstl = (u32*)slot_row;   // scratch inside the output array until row_tile_kernel (see fill_slots_kernel)
     hipLaunchKernelGGL(fill_slots_kernel, dim3(grid_for(n_slots)), dim3(256), 0, s, n_slots, bs.n_nodes, bs.tile, slot_src, slot_w, dstl);
     u32* split = ws.scan_a;       // cut position of every chunk (layout 1); n_chunks <= nmax
-    const u32 placement = bs.layout == 2 ? 0u : bs.layout;        // relation-major units: layout 0's dealing inside the one tile
+    // relation-major units: layout 0's dealing inside the one tile; layout 3: layout 0, then compact_runs_kernel
+    const u32 placement = (bs.layout == 2 || bs.layout == 3) ? 0u : bs.layout;
     hipLaunchKernelGGL(chunk_meta_kernel, dim3(grid_for(bs.n_chunks)), dim3(256), 0, s, ws.gch, ws.gstart, ws.gkey, bs.n_groups,
                        bs.n_chunks, bs.chunk, placement, ws.sb.k[bs.ubuf], bs.kl, split, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
     hipLaunchKernelGGL(place_kernel, dim3(grid_for(bs.n_unique)), dim3(256), 0, s, ws.sb.k[bs.ubuf], ws.sb.v[bs.ubuf], bs.n_unique,
@@ -818,6 +909,9 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     exclusive_scan(ucnt, ucnt, bs.n_chunks, ws.sb.sums, s);
     hipLaunchKernelGGL(emit_units_kernel, dim3(grid_for(bs.n_chunks)), dim3(256), 0, s, cb.v[cur], chunk_cnt, ucnt, bs.n_chunks,
                        bs.chunk / 64u, (int32_t*)plan->rel_order);
+    if (bs.layout == 3)      // last: the unit list above is layout 0's (nothing walks it on a layout-3 plan)
+        hipLaunchKernelGGL(compact_runs_kernel, dim3(grid_for(bs.n_chunks, 64)), dim3(64), 0, s, bs.n_chunks, bs.n_nodes, bs.tile, bs.n_own,
+                           chunk_rel, chunk_tile, chunk_cnt, chunk_flags, slot_src, slot_w, slot_row, slot_acc);
     plan->n_nodes = (int32_t)bs.n_nodes;
     plan->n_owned = (int32_t)bs.n_own;
     plan->num_relations = (int32_t)bs.num_rel;

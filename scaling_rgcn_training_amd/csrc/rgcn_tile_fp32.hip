@@ -74,8 +74,11 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
         TileArgs b = a;
         b.wp = packed + (size_t)(plan->num_relations + 1) * KP * NP;
         const int st3 = launch_tile3p(b, plan->n_tiles, plan->layout, stream);
-        if (st3 != RGCN_ERR_LDS) return st3;
+        if (st3 != RGCN_ERR_LDS || plan->layout == 3) return st3;
     }
+    // layout 3 (runs of equal (destination, relation) on ONE slot, their other rows in shadow row tiles): only the kernel above
+    // adds the shadows
+    if (plan->layout == 3) return RGCN_ERR_PLAN;
     return dispatch_tile(KP, NP, a, plan->n_tiles, plan->chunk, (hipStream_t)stream);
 }
 

@@ -66,7 +66,8 @@ class TilePlan:
                           #   None for plans built on the device
     slot_row: Tensor      # int32 [n_chunks * chunk]  row inside the owned range = tile index * tile + slot_dstl (padding: n_owned)
     slot_acc: Tensor      # int32 [n_chunks * chunk]  run-end position << 24 | accumulator row
-    layout: int = 0       # 0: rows of a group dealt over all its row tiles; 1: team placement (team_placement)
+    layout: int = 0       # 0: rows of a group dealt over all its row tiles; 1: team placement (team_placement);
+    #                       3: layout 0 with the runs of equal (destination, relation) on one slot each (compact_runs)
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -109,12 +110,15 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
 
     gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src).
     chunk: edge slots per chunk (one of CHUNKS).
-    split: the TEAM placement (layout 1, 128-slot chunks only), see ``team_placement``.
+    split: the plan layout -- False / 0: layout 0; True / 1: the TEAM placement (128-slot chunks only), see ``team_placement``;
+           3: layout 0 followed by ``compact_runs`` (128-slot chunks only).
     """
     if chunk not in CHUNKS:
         raise ValueError(f"chunk must be one of {CHUNKS}")
     if split and chunk != 128:
-        raise ValueError("the team placement needs 128-slot chunks")
+        raise ValueError("the team placement and the run compaction need 128-slot chunks")
+    if int(split) == 3:
+        return compact_runs(build_plan(gather, scatter, rel, w, n_nodes, num_relations, tile, node_begin, node_end, chunk, False))
     CHUNK = chunk  # noqa: N806  (shadows the module default inside this function)
     if node_end is None:
         node_end = n_nodes
@@ -222,6 +226,116 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
                     slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags,
                     layout=1 if split else 0)
+
+
+def compact_runs(plan: TilePlan) -> TilePlan:
+    """Twin of ``compact_runs_kernel`` (csrc/rgcn_plan.hip): a layout-0 plan with 128-slot chunks -> layout 3.  The rows of a
+    (destination, relation) run all go through the same W_r into the same output row, so the producers of ``rgcn_tile3p_kernel``
+    may add them in fp32 before they cut them (aggregate, then transform -- the reference's own order) and the run takes ONE slot.
+    Chunk-local, and only where it is simple: chunks that are a whole (tile, relation) group, runs of at most 3 rows, at most 32
+    runs of 2+ rows and 16 of 3; any other chunk keeps its layout-0 slots.  New chunk: heads (first row of every run; runs of 3
+    first, then of 2, then single rows, each class in destination order) on slots 0 .. H-1; the second row of head h on row tile
+    7 - h // 16, place h % 16; the third on row tile 5, place h.  ``chunk_cnt`` = 16 ceil(H / 16); ``chunk_flags`` bits 16-17 = row
+    tiles with second rows, bit 18 = a row tile with third rows, bit 19 = some run's rows differ in weight (the producers then
+    scale a shadow row by its weight / its head's weight -- the float32 in the shadow's ``slot_acc`` -- before they add it).  Every
+    slot keeps its own weight and its run's row (a walk over all slots with a weight still sums the layer: tests/plan_emulator.py).
+    Plain loops over the chunks: small plans (tests) only."""
+    if plan.chunk != 128 or plan.layout != 0:
+        raise ValueError("compact_runs wants a layout-0 plan with 128-slot chunks")
+    if plan.n_chunks == 0:
+        plan.layout = 3
+        return plan
+    dev = plan.slot_src.device
+    tile, n_nodes, n_own = plan.tile, plan.n_nodes, plan.n_owned
+    src = plan.slot_src.cpu().numpy().copy()
+    wbits = plan.slot_w.cpu().numpy().copy().view("uint32")
+    row = plan.slot_row.cpu().numpy().copy()
+    acc = plan.slot_acc.cpu().numpy().copy()
+    cnt = plan.chunk_cnt.cpu().numpy().copy()
+    flags = plan.chunk_flags.cpu().numpy().copy()
+    crel = plan.chunk_rel.cpu().numpy()
+    ctile = plan.chunk_tile.cpu().numpy()
+    dstl = None if plan.slot_dstl is None else plan.slot_dstl.cpu().numpy().copy()
+    pad_acc = (15 << 24) | tile
+
+    def ratio(ws_bits, wh_bits):          # float32 bits of (shadow weight / head weight), IEEE division as on the device
+        import numpy as np
+        q = np.array([ws_bits], dtype=np.uint32).view(np.float32) / np.array([wh_bits], dtype=np.uint32).view(np.float32)
+        return int(q.astype(np.float32).view(np.int32)[0])
+
+    for c in range(plan.n_chunks):
+        if c > 0 and crel[c - 1] == crel[c] and ctile[c - 1] == ctile[c]:
+            continue
+        if c + 1 < plan.n_chunks and crel[c + 1] == crel[c] and ctile[c + 1] == ctile[c]:
+            continue
+        nt = int(cnt[c]) // 16
+        if nt == 0:
+            continue
+        base = c * 128
+        tbase = int(ctile[c]) * tile
+        rows = []
+        for j in range(nt * 16):
+            sl = base + (j % nt) * 16 + j // nt
+            if int(src[sl]) == n_nodes:
+                break
+            rows.append((int(src[sl]), int(row[sl]) - tbase, int(wbits[sl])))
+        runs, j, ok, uneq = [], 0, True, 0
+        while j < len(rows):
+            ln = 1
+            while j + ln < len(rows) and rows[j + ln][1] == rows[j][1]:
+                if rows[j + ln][2] != rows[j][2]:
+                    uneq = 1
+                ln += 1
+            if ln > 3:
+                ok = False
+            runs.append((j, ln))
+            j += ln
+        if not ok:
+            continue
+        n1 = sum(1 for _, ln in runs if ln == 1)
+        n2 = sum(1 for _, ln in runs if ln == 2)
+        n3 = sum(1 for _, ln in runs if ln == 3)
+        if n2 + n3 == 0 or n3 > 16 or n2 + n3 > 32:
+            continue
+        heads = n1 + n2 + n3
+        nh, ns1, ns2 = (heads + 15) // 16, (n2 + n3 + 15) // 16, 1 if n3 else 0
+        if nh >= nt or nh > (5 if ns2 else 8 - ns1):
+            continue
+        src[base:base + 128] = n_nodes
+        wbits[base:base + 128] = 0
+        row[base:base + 128] = n_own
+        acc[base:base + 128] = pad_acc
+        if dstl is not None:
+            dstl[base:base + 128] = tile
+        nxt = {3: 0, 2: n3, 1: n3 + n2}
+        for j0, ln in runs:
+            h = nxt[ln]
+            nxt[ln] += 1
+            s0, d0, w0 = rows[j0]
+            src[base + h], wbits[base + h], row[base + h] = s0, w0, tbase + d0
+            acc[base + h] = ((h & 15) << 24) | d0
+            if dstl is not None:
+                dstl[base + h] = d0
+            if ln >= 2:
+                s1 = base + (7 - h // 16) * 16 + (h & 15)
+                src[s1], wbits[s1], row[s1] = rows[j0 + 1][0], rows[j0 + 1][2], tbase + d0
+                acc[s1] = ratio(rows[j0 + 1][2], w0)
+            if ln == 3:
+                s2 = base + 5 * 16 + h
+                src[s2], wbits[s2], row[s2] = rows[j0 + 2][0], rows[j0 + 2][2], tbase + d0
+                acc[s2] = ratio(rows[j0 + 2][2], w0)
+        cnt[c] = nh * 16
+        flags[c] = (ns1 << 16) | (ns2 << 18) | (uneq << 19)
+    plan.slot_src = torch.from_numpy(src).to(dev)
+    plan.slot_w = torch.from_numpy(wbits.view("float32")).to(dev)
+    plan.slot_row = torch.from_numpy(row).to(dev)
+    plan.slot_acc = torch.from_numpy(acc).to(dev)
+    plan.chunk_cnt = torch.from_numpy(cnt).to(dev)
+    plan.chunk_flags = torch.from_numpy(flags).to(dev)
+    if dstl is not None:
+        plan.slot_dstl = torch.from_numpy(dstl).to(dev)
+    plan.layout = 3
+    return plan
 
 
 def team_placement(dstl: Tensor, gcnt: Tensor, grp_of_edge: Tensor, rank: Tensor, chunk_base: Tensor,
@@ -590,7 +704,7 @@ def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_
     """LRU over (edge tensors' identity, layout): at most ``_CACHE_MAX`` entries and ``RGCN_PLAN_CACHE_GB`` (48) GiB of
     plan arrays (4.3 GB per 100M edges), least recently used evicted first."""
     key = (edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape), edge_index._version,
-           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr, bool(split), bool(dw_tiles),
+           edge_type._version, str(edge_index.device), n_nodes, num_relations, tile, chunk, aggr, int(split), bool(dw_tiles),
            paths if isinstance(paths, str) else tuple(paths), widths) + tuple(extra_key)
     hit = _CACHE.pop(key, None)
     if hit is not None:

@@ -17,8 +17,9 @@ ARRAYS = ("tile_ptr", "chunk_rel", "chunk_cnt", "chunk_tile", "chunk_flags", "re
 
 def _compare(ei, et, n, r, tile, chunk, aggr="mean", fr=None, br=None, split=False):
     from scaling_rgcn_training_amd import plan as P
-    if chunk == 128 and not split:          # every 128-slot case also in the split placement (plan layout 1)
-        _compare(ei, et, n, r, tile, chunk, aggr, fr, br, split=True)
+    if chunk == 128 and not split:          # every 128-slot case also in the split placement (plan layout 1) and with the
+        _compare(ei, et, n, r, tile, chunk, aggr, fr, br, split=True)       # (destination, relation) runs compacted (layout 3)
+        _compare(ei, et, n, r, tile, chunk, aggr, fr, br, split=3)
     dev_plans = P.build_graph_plans_device(ei, et, n, r, tile, aggr, fr, br, chunk, split=split)
     ref_plans = P.build_graph_plans_torch(ei, et, n, r, tile, aggr, fr, br, chunk, split=split)
     torch.cuda.synchronize()
@@ -47,6 +48,7 @@ def test_plan_build_matches_torch_on_golden_topologies(golden, tile, chunk):
 
 
 @pytest.mark.parametrize("n,e,r,tile,chunk,skew", [(1500, 20000, 9, 64, 64, False), (3000, 60000, 5, 128, 128, False),
+                                                   (20000, 60000, 32, 224, 128, False), (3000, 30000, 32, 224, 128, False),
                                                    (4000, 60000, 5, 352, 128, True), (37, 0, 3, 16, 64, False),
                                                    (100000, 1200000, 45, 96, 64, True), (50, 5000, 2, 16, 128, False)])
 def test_plan_build_matches_torch_on_random_graphs(n, e, r, tile, chunk, skew):
