@@ -91,7 +91,8 @@ typedef struct rgcn_plan {
                             * 3 (chunk = 128): layout 0 with the rows of a (destination, relation) run on ONE slot where a chunk is
                             * a whole (tile, relation) group with runs of at most 3 rows: heads on slots 0 .. H-1, second rows on
                             * row tile 7 - h / 16 (place h % 16), third rows on row tile 5; chunk_cnt counts the head row tiles,
-                            * chunk_flags bits 16-17 / 18 the row tiles of second / third rows, bit 19 "the rows of a run differ in
+                            * chunk_flags bits 20-23 repeat every chunk's row-tile count, bits 16-17 / 18 count the row tiles of
+                            * second / third rows, bit 19 "the rows of a run differ in
                             * weight" (a shadow slot's slot_acc then holds the float weight / head's weight).  Walked by rgcn_fwd / rgcn_bwd_dx with RGCN_FLAG_SPLIT_PRODUCERS on 64 x 64 layers only (the
                             * producer waves add a run's rows before they cut them: aggregate, then transform); every other
                             * entry point answers RGCN_ERR_PLAN */

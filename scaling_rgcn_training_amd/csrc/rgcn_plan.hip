@@ -497,7 +497,8 @@ __global__ void row_tile_kernel(const u32* dstl, u32 n_row_tiles, u32 chunk, u32
 // and 16 of 3; anything else keeps its layout-0 slots (always correct: the kernel reads the shadow counts per chunk).  New chunk:
 // heads (first row of every run; runs of 3 first, then of 2, then single rows, each class in destination order) on slots 0 .. H-1;
 // the second row of head h on row tile 7 - h / 16, place h % 16; the third on row tile 5, place h -- the SAME lane of the same
-// producer wave holds a head and its shadows, one row tile register apart.  chunk_cnt = 16 ceil(H / 16); chunk_flags bits 16-17 =
+// producer wave holds a head and its shadows, one row tile register apart.  chunk_cnt = 16 ceil(H / 16); chunk_flags bits 20-23 =
+// the chunk's row tiles (every chunk of the plan, compacted or not), bits 16-17 =
 // row tiles with second rows, bit 18 = a row tile with third rows, bit 19 = some run's rows differ in weight (the transposed
 // plan: 1 / c of each edge's own destination): the producers then scale a shadow row by (its weight / its head's weight) -- the
 // float in the shadow slot's slot_acc -- before they add it, and the consumers apply the head's weight as ever.  Every slot
@@ -509,9 +510,10 @@ __global__ void compact_runs_kernel(u32 n_chunks, u32 n_nodes, u32 tile, u32 n_o
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const int32_t rel = chunk_rel[c], t = chunk_tile[c];
+    const u32 nt = (u32)chunk_cnt[c] / 16u;
+    chunk_flags[c] |= (int32_t)(nt << 20);      // every chunk: its row tiles beside its flags (one scalar word for the producers)
     if (c > 0 && chunk_rel[c - 1] == rel && chunk_tile[c - 1] == t) return;
     if (c + 1 < n_chunks && chunk_rel[c + 1] == rel && chunk_tile[c + 1] == t) return;
-    const u32 nt = (u32)chunk_cnt[c] / 16u;
     if (nt == 0) return;
     const size_t base = (size_t)c * 128u;
     int32_t lsrc[128], ld[128];
@@ -577,7 +579,7 @@ __global__ void compact_runs_kernel(u32 n_chunks, u32 n_nodes, u32 tile, u32 n_o
         j += len;
     }
     chunk_cnt[c] = (int32_t)(nh * 16u);
-    chunk_flags[c] = (int32_t)((ns1 << 16) | (ns2 << 18) | (uneq << 19));
+    chunk_flags[c] = (int32_t)((ns1 << 16) | (ns2 << 18) | (uneq << 19) | (nh << 20));
 }
 
 __global__ void tile_ptr_kernel(const int32_t* __restrict__ chunk_tile, u32 n_chunks, u32 n_tiles, int32_t* __restrict__ tile_ptr) {

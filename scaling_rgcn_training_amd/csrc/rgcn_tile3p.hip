@@ -98,9 +98,9 @@ __device__ __forceinline__ unsigned p3_cvt_pk_bf16(float lo, float hi) {      //
 // 256-byte dma4 per wave and chunk).
 struct P3Rows {     // what one producer batch loads: set j % 3 holds chunk j
     f32x4 v[8];    // the wave's 32 rows of chunk j (lane: 16-byte piece c of row 4 i + rq)
-    int meta;      // this lane's word of chunk j's weights (waves 0, 1) or run metadata (waves 2, 3)
+    int meta;      // chunk j's metadata of the wave's OWN 32 rows: lanes 0..31 their weights, lanes 32..63 their slot_acc words
+                   // (run metadata; in a layout-3 chunk with flag bit 19 a shadow row's weight / its head's weight)
     int idx;       // row indices of chunk j + 2 (lanes 0..31)
-    int wrow;      // slot_acc of the wave's 32 rows of chunk j (lanes 0..31, as idx): a shadow row's weight ratio (layout 3, bit 19)
 };
 
 // Every vector-memory operation of a producer wave is an inline-asm load into registers, waited for by ONE s_waitcnt
@@ -125,9 +125,9 @@ __device__ __forceinline__ void p3_load_int(int& dst, const int* p) {
 // that no use of them can be scheduled above the wait
 template <int N>
 __device__ __forceinline__ void p3_wait_batch(P3Rows& r) {
-    asm volatile("s_waitcnt vmcnt(%11)"
+    asm volatile("s_waitcnt vmcnt(%10)"
                  : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
-                   "+v"(r.meta), "+v"(r.idx), "+v"(r.wrow)
+                   "+v"(r.meta), "+v"(r.idx)
                  : "n"(N)
                  : "memory");
 }
@@ -159,10 +159,6 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
         const int kk = k < nch ? k : nch - 1;
         return a.slot_src + (size_t)(c0 + kk) * kP3CH + 16 * ((lane & 31) >> 2) + 4 * pw + (lane & 3);      // lane 4 i + rq: row 16 i + 4 pw + rq
     };
-    auto wrow_ptr = [&](int k) {          // the same lanes' slot_acc words (row 16 i + 4 pw + rq in lane 4 i + rq)
-        const int kk = k < nch ? k : nch - 1;
-        return a.slot_acc + (size_t)(c0 + kk) * kP3CH + 16 * ((lane & 31) >> 2) + 4 * pw + (lane & 3);
-    };
     auto issue_loads = [&](P3Rows& r, int idxv) {
         int idx[8];
 #pragma unroll
@@ -176,38 +172,43 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
             p3_load_rows(r.v[i], rsrc, __umul24((unsigned)idx[i], rowb) + coff);
         }
     };
+    // the ring's metadata: [2][128] pairs {weight, run metadata} -- one 8-byte read per row tile for the consumers.  A wave moves
+    // the two words of its OWN 32 rows (lane & 31 <-> row 16 i + 4 pw + rq as for the indices; lanes 0..31 the weight, 32..63 the
+    // slot_acc word), so that the weight ratio of a layout-3 shadow row is in the wave that adds that row
+    // (plans without such rows keep the round-2 mapping: waves 0, 1 the weights of slots 0..63 / 64..127, waves 2, 3 the slot_acc
+    // words -- two coalesced 256-byte loads)
+    const int mrow = 16 * ((lane & 31) >> 2) + 4 * pw + (lane & 3);
     const int half = pw & 1;
-    const int* meta_src = (pw < 2 ? (const int*)a.slot_w : a.slot_acc) + 64 * half + lane;
-    // the ring's metadata: [2][128] pairs {weight, run metadata} -- one 8-byte read per row tile for the consumers
-    int* meta_dst = (int*)wring + 2 * (64 * half + lane) + (pw < 2 ? 0 : 1);
+    const int* meta_src = a.merged ? (lane < 32 ? (const int*)a.slot_w : a.slot_acc) + mrow
+                                   : (pw < 2 ? (const int*)a.slot_w : a.slot_acc) + 64 * half + lane;
+    int* meta_dst = a.merged ? (int*)wring + 2 * mrow + (lane >> 5) : (int*)wring + 2 * (64 * half + lane) + (pw < 2 ? 0 : 1);
     auto issue_meta = [&](P3Rows& r, int k) { p3_load_int(r.meta, meta_src + (size_t)(c0 + k) * kP3CH); };
     auto store_meta = [&](const P3Rows& r, int k) { meta_dst[(k & 1) * 2 * kP3CH] = r.meta; };
     // fl: the chunk's flags -- bits 16-17 / 18 of a layout-3 chunk (rgcn_plan.hip compact_runs_kernel): row tiles 7, 6 hold the
     // second rows of the (destination, relation) runs whose first rows sit in row tiles 0, 1, row tile 5 the third rows of row
-    // tile 0's: same lane, added in fp32 before the cut (aggregate, then transform); bit 19: a shadow row times its weight ratio first
-    auto split_store = [&](const P3Rows& r, int k, int nrt, int fl) {
+    // tile 0's: same lane, added in fp32 before the cut (aggregate, then transform); bit 19: a shadow row times its weight ratio
+    // first.  One uniform branch where a chunk has no shadows; the sums replace the head rows in place (the set is reloaded anyway).
+    auto split_store = [&](P3Rows& r, int k, int nrt, int fl) {
         char* slot = ring + (k & 1) * kP3SlotBytes;
-        const int ns1 = (fl >> 16) & 3;
-        const bool ns2 = ((fl >> 18) & 1) != 0, pre = ((fl >> 19) & 1) != 0;
+        if (fl & (7 << 16)) {
+            const int ns1 = (fl >> 16) & 3;
+            const bool ns2 = ((fl >> 18) & 1) != 0, pre = ((fl >> 19) & 1) != 0;
+            if (pre) {      // the rows of a run differ in weight -- a shadow row times (its weight / its head's)
+                auto wt = [&](int t) { return __int_as_float(__builtin_amdgcn_ds_bpermute((32 + 4 * t + rq) * 4, r.meta)); };
+                r.v[0] += r.v[7] * wt(7);
+                if (ns2) r.v[0] += r.v[5] * wt(5);
+                if (ns1 >= 2) r.v[1] += r.v[6] * wt(6);
+            } else {
+                r.v[0] += r.v[7];
+                if (ns2) r.v[0] += r.v[5];
+                if (ns1 >= 2) r.v[1] += r.v[6];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (i >= nrt) break;                   // row tiles the chunk does not use
             const int row = 16 * i + 4 * pw + rq;
-            f32x4 vi = r.v[i];
-            if (pre) {      // bit 19: the rows of a run differ in weight -- a shadow row times (its weight / its head's)
-                auto wt = [&](int t) { return __int_as_float(__builtin_amdgcn_ds_bpermute((4 * t + rq) * 4, r.wrow)); };
-                if (i == 0) {
-                    if (ns1 >= 1) vi += r.v[7] * wt(7);
-                    if (ns2) vi += r.v[5] * wt(5);
-                }
-                if (i == 1 && ns1 >= 2) vi += r.v[6] * wt(6);
-            } else {
-                if (i == 0) {
-                    if (ns1 >= 1) vi += r.v[7];
-                    if (ns2) vi += r.v[5];
-                }
-                if (i == 1 && ns1 >= 2) vi += r.v[6];
-            }
+            const f32x4 vi = r.v[i];
             float x0 = vi[0], x1 = vi[1], x2 = vi[2], x3 = vi[3];
             if (RGCN_P3_ABL & 8) {
                 char* p8 = slot + row * 128 + (((c >> 1) ^ ((row >> 1) & 7)) << 4) + ((c & 1) << 3);
@@ -242,20 +243,16 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
             *(uint2*)(p + 2 * kP3PlaneBytes) = make_uint2(l0, l1);
         }
     };
-    // rows + metadata + shadow ratios of chunk j, indices of chunk j + 2: 11 loads.  need_w: chunk j's producers scale its shadow
-    // rows (flags bit 19); otherwise that load reads one fixed line (no memory traffic; the count of loads in flight stays)
-    auto issue_batch = [&](P3Rows& r, int j, int idx_rows, bool need_w) {
+    auto issue_batch = [&](P3Rows& r, int j, int idx_rows) {      // rows + metadata of chunk j, indices of chunk j + 2: 10 loads
         issue_loads(r, idx_rows);
         issue_meta(r, j < nch ? j : nch - 1);
-        p3_load_int(r.wrow, need_w ? wrow_ptr(j) : a.slot_acc + (lane & 31));
         p3_load_int(r.idx, idx_ptr(j + 2));
     };
-    auto scales = [&](int k) { return ((ldc(a.chunk_flags, c0 + (k < nch ? k : nch - 1)) >> 19) & 1) != 0; };
     P3Rows r0, r1, r2;
     auto clear = [&](P3Rows& r) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) r.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        r.meta = r.idx = r.wrow = 0;
+        r.meta = r.idx = 0;
     };
     clear(r0); clear(r1); clear(r2);
     // prologue: indices of chunks 0 and 1, then the batches of chunks 0, 1, 2
@@ -264,16 +261,20 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     p3_wait_batch<0>(r1);
     p3_wait_batch<0>(r2);
     const int i0 = r1.idx, i1 = r2.idx;
-    issue_batch(r0, 0, i0, scales(0));             // + indices of chunk 2
-    issue_batch(r1, 1, i1, scales(1));             // + indices of chunk 3
-    p3_wait_batch<11>(r0);                         // all but the youngest batch: rows of chunk 0, indices of chunk 2
-    issue_batch(r2, 2, r0.idx, scales(2));         // + indices of chunk 4
-    bool sc_next = scales(3);                      // of chunk it + 3, fetched an iteration ahead (scalar load)
-    auto tiles_of = [&](int k) { return (ldc(a.chunk_cnt, c0 + (k < nch ? k : nch - 1)) + 15) >> 4; };
-    auto flags_of = [&](int k) { return ldc(a.chunk_flags, c0 + (k < nch ? k : nch - 1)); };
-    int nrt_next = tiles_of(1);                    // row tiles of chunk it + 1, fetched an iteration ahead (scalar load)
-    int fl_next = flags_of(1);
-    split_store(r0, 0, tiles_of(0), flags_of(0));
+    issue_batch(r0, 0, i0);                        // + indices of chunk 2
+    issue_batch(r1, 1, i1);                        // + indices of chunk 3
+    p3_wait_batch<10>(r0);                         // all but the youngest batch: rows of chunk 0, indices of chunk 2
+    issue_batch(r2, 2, r0.idx);                    // + indices of chunk 4
+    // one scalar word per chunk, fetched an iteration ahead: the chunk's slot count, or on a layout-3 plan its flags, whose bits
+    // 20-23 repeat the row-tile count (compact_runs_kernel) beside the shadow counts
+    auto word_of = [&](int k) { return ldc(a.merged ? a.chunk_flags : a.chunk_cnt, c0 + (k < nch ? k : nch - 1)); };
+    auto tiles_in = [&](int wd) { return a.merged ? (wd >> 20) & 15 : (wd + 15) >> 4; };
+    auto flags_in = [&](int wd) { return a.merged ? wd : 0; };
+    int wd_next = word_of(1);
+    {
+        const int wd0 = word_of(0);
+        split_store(r0, 0, tiles_in(wd0), flags_in(wd0));
+    }
     store_meta(r0, 0);
     wg_barrier();                                  // chunk 0 (and the accumulator init) visible
     // (batches are issued for chunks past the end too, from clamped addresses: the count of operations in flight stays what
@@ -283,19 +284,16 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
 #endif
     auto step = [&](int it, P3Rows& tgt, P3Rows& src) {      // tgt = set it % 3, src = set (it + 1) % 3
         P3S(q0);
-        p3_wait_batch<11>(src);
+        p3_wait_batch<10>(src);
         __builtin_amdgcn_sched_barrier(0);
         P3S(q1);
-        const bool sc_now = sc_next;
-        sc_next = scales(it + 4);
-        if (it + 1 < nch) issue_batch(tgt, it + 3, src.idx, sc_now);
+        if (it + 1 < nch) issue_batch(tgt, it + 3, src.idx);
         __builtin_amdgcn_sched_barrier(0);
         P3S(q2);
-        const int nrt_now = nrt_next, fl_now = fl_next;
-        nrt_next = tiles_of(it + 2);
-        fl_next = flags_of(it + 2);
+        const int wd_now = wd_next;
+        wd_next = word_of(it + 2);
         if (it + 1 < nch) {
-            split_store(src, it + 1, nrt_now, fl_now);
+            split_store(src, it + 1, tiles_in(wd_now), flags_in(wd_now));
             store_meta(src, it + 1);
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -235,8 +235,8 @@ def compact_runs(plan: TilePlan) -> TilePlan:
     Chunk-local, and only where it is simple: chunks that are a whole (tile, relation) group, runs of at most 3 rows, at most 32
     runs of 2+ rows and 16 of 3; any other chunk keeps its layout-0 slots.  New chunk: heads (first row of every run; runs of 3
     first, then of 2, then single rows, each class in destination order) on slots 0 .. H-1; the second row of head h on row tile
-    7 - h // 16, place h % 16; the third on row tile 5, place h.  ``chunk_cnt`` = 16 ceil(H / 16); ``chunk_flags`` bits 16-17 = row
-    tiles with second rows, bit 18 = a row tile with third rows, bit 19 = some run's rows differ in weight (the producers then
+    7 - h // 16, place h % 16; the third on row tile 5, place h.  ``chunk_cnt`` = 16 ceil(H / 16); ``chunk_flags`` bits 20-23 = the chunk's
+    row tiles (every chunk, compacted or not), bits 16-17 = row tiles with second rows, bit 18 = a row tile with third rows, bit 19 = some run's rows differ in weight (the producers then
     scale a shadow row by its weight / its head's weight -- the float32 in the shadow's ``slot_acc`` -- before they add it).  Every
     slot keeps its own weight and its run's row (a walk over all slots with a weight still sums the layer: tests/plan_emulator.py).
     Plain loops over the chunks: small plans (tests) only."""
@@ -264,11 +264,12 @@ def compact_runs(plan: TilePlan) -> TilePlan:
         return int(q.astype(np.float32).view(np.int32)[0])
 
     for c in range(plan.n_chunks):
+        nt = int(cnt[c]) // 16
+        flags[c] |= nt << 20           # every chunk: its row tiles beside its flags (one scalar word for the producers)
         if c > 0 and crel[c - 1] == crel[c] and ctile[c - 1] == ctile[c]:
             continue
         if c + 1 < plan.n_chunks and crel[c + 1] == crel[c] and ctile[c + 1] == ctile[c]:
             continue
-        nt = int(cnt[c]) // 16
         if nt == 0:
             continue
         base = c * 128
@@ -325,7 +326,7 @@ def compact_runs(plan: TilePlan) -> TilePlan:
                 src[s2], wbits[s2], row[s2] = rows[j0 + 2][0], rows[j0 + 2][2], tbase + d0
                 acc[s2] = ratio(rows[j0 + 2][2], w0)
         cnt[c] = nh * 16
-        flags[c] = (ns1 << 16) | (ns2 << 18) | (uneq << 19)
+        flags[c] = (ns1 << 16) | (ns2 << 18) | (uneq << 19) | (nh << 20)
     plan.slot_src = torch.from_numpy(src).to(dev)
     plan.slot_w = torch.from_numpy(wbits.view("float32")).to(dev)
     plan.slot_row = torch.from_numpy(row).to(dev)
