@@ -45,9 +45,11 @@ __device__ __forceinline__ unsigned long long p3_stamp() {
 #define P3A(acc, a, b)
 #endif
 // row tiles whose operands the consumers read ahead of the one they multiply (LDS round trip under load: 300-450 cycles,
-// 12 bf16 MFMAs: ~200)
+// 12 bf16 MFMAs: ~200).  Round 2 settled on 2; with the consumer waves at priority 3 (their reads go ahead of the producers')
+// and chunks of 4.3 row tiles (layout 3) one tile ahead is as good or better: forward / dX 8.31 / 8.39 ms against 8.40 / 8.42
+// (and 8.59 / 8.56 at 3), 8.70 / 8.64 against 8.76 / 8.72 on layout-0 plans, A/B on one box, bit-identical results
 #ifndef RGCN_P3_LA
-#define RGCN_P3_LA 2
+#define RGCN_P3_LA 1
 #endif
 // 0: round-to-nearest pieces (v_cvt_pk_bf16_f32); 1: the producers split by truncation (v_and / v_sub / v_perm_b32: exact too,
 // but measured 0.25 ms per launch SLOWER: 9.94 against 9.67 ms)
