@@ -391,11 +391,23 @@ def main():
 
     dwp = getattr(plans, "dw", None) if world == 1 else None
     psd = _lib.plan_struct(dwp) if dwp is not None else None
+    # a rank's pieces: each on the tile-major kernel with its own plan where the module built one (conv.py backward)
+    piece_dw = [] if world == 1 else [(pc.fwd, getattr(pc, "dw", None), getattr(pc, "dw_walk", None)) for pc in plans.pieces
+                                      if pc.fwd is not None and pc.fwd.n_owned > 0]
 
     def run_dw():      # what the module's backward launches (conv.py): tile-major kernel + root part, or the relation-major walk
         if psd is not None:
             _lib.bwd_dw_tiles(psd, plans.dw_walk, xd, d, dg, d, dw, kf)
             _lib.bwd_dw_root(xd, d, dg, d, dr, db)       # (the module enqueues it on a side stream beside dX: conv.py)
+            return
+        if world > 1:
+            for fp_, dwp_, walk_ in piece_dw:
+                b_, e_ = fp_.node_begin, fp_.node_end
+                if dwp_ is not None:
+                    _lib.bwd_dw_tiles(_lib.plan_struct(dwp_), walk_, xd, d, dg[b_:e_], d, dw, kf)
+                    _lib.bwd_dw_root(xd[b_:e_], d, dg[b_:e_], d, dr, db)
+                else:
+                    _lib.bwd_dw(_lib.plan_struct(fp_), xd, d, dg[b_:e_], d, dw, dr, db, kf)
             return
         for ps, p in psf:
             _lib.bwd_dw(ps, xd, d, dg[p.node_begin:p.node_end], d, dw, dr, db, kf)
