@@ -297,3 +297,51 @@ def test_team_placement_walks_and_keeps_parts_disjoint(golden, tile):
     np.testing.assert_allclose(dx, golden["d_x"], rtol=1e-6, atol=1e-6)
     dw = emulate_dw(plans.fwd, golden["x"], golden["dout"], w_all.shape[0], w_all.shape[1], w_all.shape[2])
     np.testing.assert_allclose(dw[:-1], golden["d_wfull"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,e,r,tile", [(20000, 60000, 32, 224), (3000, 30000, 32, 224), (5000, 100000, 32, 224), (300, 2500, 8, 64)])
+def test_compact_runs_keeps_the_layer_and_its_own_invariants(n, e, r, tile):
+    """plan.compact_runs (layout 3; twin of compact_runs_kernel): the walk over all slots still sums the layer (forward and
+    transposed plan, whose runs differ in weight); a compacted chunk holds pairwise distinct destinations on its head slots, every
+    shadow sits in its head's lane position (row tile 7 - h // 16 or 5, place h % 16) with its head's output row, the flags'
+    row-tile count equals chunk_cnt / 16 on EVERY chunk, and no edge row is lost."""
+    import numpy as np
+    from oracle import rgcn_oracle as O
+    from scaling_rgcn_training_amd import plan as P
+    from tests.plan_emulator import emulate_spmm
+    ei, et = O.synthetic_graph(n, e, r, seed=n + e)
+    ei[:, 40:70] = ei[:, 5:35]              # duplicate triples: merged slots of weight 2 / c inside runs of weight 1 / c
+    et[40:70] = et[5:35]
+    w, root, bias = O.synthetic_params(r, 8, 6, seed=2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 8, generator=g).double().numpy()
+    w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0).astype(np.float64)
+    ew = P.edge_weights(ei[0], ei[1], et, r, "mean")
+    some = 0
+    for gather, scatter in ((ei[0], ei[1]), (ei[1], ei[0])):
+        p0 = P.build_plan(gather, scatter, et, ew, n, r, tile, chunk=128)
+        p3 = P.build_plan(gather, scatter, et, ew, n, r, tile, chunk=128, split=3)
+        assert p3.layout == 3 and p3.n_chunks == p0.n_chunks
+        np.testing.assert_allclose(emulate_spmm(p3, x, w_all, bias.numpy()), emulate_spmm(p0, x, w_all, bias.numpy()), rtol=0, atol=1e-12)
+        fl = p3.chunk_flags.numpy().astype(np.int64)
+        cnt = p3.chunk_cnt.numpy().astype(np.int64)
+        assert np.array_equal((fl >> 20) & 15, cnt // 16)
+        assert int((p3.slot_w != 0).sum()) == int((p0.slot_w != 0).sum())
+        assert np.array_equal(np.sort(p3.slot_src.numpy()[p3.slot_src.numpy() < n]), np.sort(p0.slot_src.numpy()[p0.slot_src.numpy() < n]))
+        src = p3.slot_src.numpy().reshape(-1, 128)
+        row = p3.slot_row.numpy().reshape(-1, 128)
+        for c in np.nonzero((fl >> 16) & 7)[0]:
+            some += 1
+            ns1, ns2, nh = (fl[c] >> 16) & 3, (fl[c] >> 18) & 1, cnt[c] // 16
+            heads = row[c, :nh * 16][src[c, :nh * 16] < n]
+            assert len(set(heads.tolist())) == len(heads), "a compacted chunk's heads scatter into pairwise distinct rows"
+            assert (fl[c] & 0xFFFF) == 0, "so none of its row tiles needs the run-sum"
+            for t, head_tile, shadow in ((7, 0, ns1 >= 1), (6, 1, ns1 >= 2), (5, 0, bool(ns2))):
+                used = src[c, 16 * t:16 * t + 16] < n
+                if shadow:      # behind the head tiles, every row the output row of the head in the same place
+                    assert t >= nh and used.any()
+                    assert np.array_equal(row[c, 16 * t:16 * t + 16][used], row[c, 16 * head_tile:16 * head_tile + 16][used])
+                elif t >= nh:
+                    assert not used.any()
+            assert nh <= (5 if ns2 else 8 - ns1)
+    assert some > 0 or e > 64 * n, "no chunk was compacted: the case tests nothing"
