@@ -231,7 +231,7 @@ int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int din, const
 /* d_weight alone, tile-major (64 x 64 layers with at most 32 relations on large graphs): every wave owns one relation and
  * keeps its 64 x 64 accumulator in registers for the whole launch, the upstream-gradient rows of a tile are staged in LDS
  * once per relation quarter instead of being gathered per edge (37 GB instead of 55 GB moved at the headline config).
- * `plan`: a FORWARD-direction plan built with the geometry rgcn_dw_tiles_geometry reports (tile = 304, chunk = 64, layout
+ * `plan`: a FORWARD-direction plan built with the geometry rgcn_dw_tiles_geometry reports (tile = 320, chunk = 64, layout
  * 0); walk_ptr: int32 [num_relations][walkers + 1], walk_ptr[r][p] = first position in plan->rel_order of relation r
  * whose tile is >= p * n_tiles / walkers (integer division), walk_ptr[r][walkers] = end of relation r; filled by
  * rgcn_dw_tiles_walk (once per plan; walk_ptr: device memory, num_relations * (walkers + 1) int32).

@@ -33,7 +33,7 @@ def _worker(rank, world, port, ret, dw_direct):
     from scaling_rgcn_training_amd.conv import RGCNConv
     dev = torch.device("cuda:0")
     # "0" / "2": pin the relation-major dW kernel (ring / direct) on every piece; "tiles": the default of 64 x 64 layers on
-    # large graphs -- every piece on the tile-major kernel with its own T = 304 plan -- reached here by lowering the
+    # large graphs -- every piece on the tile-major kernel with its own T = 320 plan -- reached here by lowering the
     # edge-count threshold; "skew": the same on a hub graph, whose cut follows the edge counts (unequal blocks, broadcasts)
     from scaling_rgcn_training_amd import conv as C
     flags = {"0": _lib.FLAG_DW_RING, "2": _lib.FLAG_DW_DIRECT}.get(dw_direct, 0)

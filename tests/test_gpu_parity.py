@@ -568,7 +568,7 @@ def test_tile_major_dw_through_the_module(dev, monkeypatch, split):
     xd = x.to(dev).requires_grad_(True)
     out = conv(xd, eid, etd)
     plans = conv._plans(xd, eid, etd)
-    assert plans.dw is not None and plans.dw.tile == 304            # the tile-major plan exists: backward takes that path
+    assert plans.dw is not None and plans.dw.tile == C._lib.dw_tiles_geometry()[0]            # the tile-major plan exists: backward takes that path
     out.backward(dg.to(dev))
     torch.cuda.synchronize()
     c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
