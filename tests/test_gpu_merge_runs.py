@@ -115,3 +115,13 @@ def test_the_module_picks_layout_3_and_agrees_with_layout_0(dev):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
     for a, b in zip(res[True][2:], res[False][2:]):
         assert torch.equal(a, b)          # the weight gradients never see the forward / transposed plans
+
+
+def test_layout_3_needs_128_slot_chunks(dev):
+    from scaling_rgcn_training_amd import _lib, plan as P
+    ei, et = O.synthetic_graph(500, 4000, 4, seed=2)
+    with pytest.raises(_lib.RgcnLibraryError) as err:
+        P.build_graph_plans_device(ei.to(dev), et.to(dev), 500, 4, 64, "mean", None, None, 64, split=3)
+    assert err.value.status == _lib.ERR_PLAN
+    with pytest.raises(ValueError):
+        P.build_graph_plans_torch(ei, et, 500, 4, 64, "mean", None, None, 64, split=3)
