@@ -503,7 +503,8 @@ __global__ void row_tile_kernel(const u32* dstl, u32 n_row_tiles, u32 chunk, u32
 // plan: 1 / c of each edge's own destination): the producers then scale a shadow row by (its weight / its head's weight) -- the
 // float in the shadow slot's slot_acc -- before they add it, and the consumers apply the head's weight as ever.  Every slot
 // keeps its own weight and its run's row (a walk over all slots with a weight -- tests/plan_emulator.py -- still sums the layer).
-__global__ void compact_runs_kernel(u32 n_chunks, u32 n_nodes, u32 tile, u32 n_own, const int32_t* __restrict__ chunk_rel,
+constexpr int kCompactThreads = 32;
+__global__ void __launch_bounds__(kCompactThreads) compact_runs_kernel(u32 n_chunks, u32 n_nodes, u32 tile, u32 n_own, const int32_t* __restrict__ chunk_rel,
                                     const int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_cnt,
                                     int32_t* __restrict__ chunk_flags, int32_t* __restrict__ slot_src, float* __restrict__ slot_w,
                                     int32_t* __restrict__ slot_row, int32_t* __restrict__ slot_acc) {
@@ -516,8 +517,13 @@ __global__ void compact_runs_kernel(u32 n_chunks, u32 n_nodes, u32 tile, u32 n_o
     if (c + 1 < n_chunks && chunk_rel[c + 1] == rel && chunk_tile[c + 1] == t) return;
     if (nt == 0) return;
     const size_t base = (size_t)c * 128u;
-    int32_t lsrc[128], ld[128];
-    u32 lw[128];
+    // the chunk's rows in sorted order: a copy per thread in LDS (32 threads x 3 x 129 words; the odd stride keeps the threads on
+    // different banks) -- as private arrays they lived in scratch memory: 67 GB of traffic for a 100M-edge plan
+    __shared__ int32_t s_src[kCompactThreads][129], s_d[kCompactThreads][129];
+    __shared__ u32 s_w[kCompactThreads][129];
+    int32_t* lsrc = s_src[threadIdx.x];
+    int32_t* ld = s_d[threadIdx.x];
+    u32* lw = s_w[threadIdx.x];
     u32 n = 0;
     const u32 tbase = (u32)t * tile;
     for (u32 j = 0; j < nt * 16u; ++j) {
@@ -912,7 +918,7 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     hipLaunchKernelGGL(emit_units_kernel, dim3(grid_for(bs.n_chunks)), dim3(256), 0, s, cb.v[cur], chunk_cnt, ucnt, bs.n_chunks,
                        bs.chunk / 64u, (int32_t*)plan->rel_order);
     if (bs.layout == 3)      // last: the unit list above is layout 0's (nothing walks it on a layout-3 plan)
-        hipLaunchKernelGGL(compact_runs_kernel, dim3(grid_for(bs.n_chunks, 64)), dim3(64), 0, s, bs.n_chunks, bs.n_nodes, bs.tile, bs.n_own,
+        hipLaunchKernelGGL(compact_runs_kernel, dim3(grid_for(bs.n_chunks, kCompactThreads)), dim3(kCompactThreads), 0, s, bs.n_chunks, bs.n_nodes, bs.tile, bs.n_own,
                            chunk_rel, chunk_tile, chunk_cnt, chunk_flags, slot_src, slot_w, slot_row, slot_acc);
     plan->n_nodes = (int32_t)bs.n_nodes;
     plan->n_owned = (int32_t)bs.n_own;
