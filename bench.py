@@ -215,6 +215,95 @@ def gpu_rung(n, e, r, din, dout, dev, steps=20, warmup=5, graph=False, num_bases
     return ms, plan_s, ms_graph, stats
 
 
+def emulate_world(weight, root, ei, et, x, dg, dev, world, single_step_ms, steps=12, warmup=3, pieces_list=(1, 2, 4),
+                  exchanges=("full", "needed"), ranks=None):
+    """ONE GPU standing in for one rank of a ``world``-rank job (no process group, no collectives): the rank's plans of the
+    world-``world`` cut built as dist.rank_plans builds them, its forward / dX / d_weight launches over its pieces into the
+    full-size buffers, the packing and scattering of the rows an exchange = "needed" run would send and receive -- everything a
+    rank does per step except the bytes on the wire.  Per (pieces, exchange, rank): median HIP-event ms of the forward part and
+    of the backward part of a step (``rank_share_ms`` = their sum) next to ``single_step_ms / world``, the rows the rank would
+    receive, and a step time PREDICTED from those measurements and a link rate: forward = max(K_f + c / p, K_f / p + c) (the
+    exchange of piece s runs under the kernels of piece s + 1; the last piece's is exposed), backward = max(K_b, K_f / p + c)
+    (the dX exchange stays in flight under the weight-gradient kernels, conv.py), c = bytes per link and gather / rate with
+    all world - 1 links of a GPU busy at once (xGMI is point to point)."""
+    from scaling_rgcn_training_amd import dist as rdist
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    from scaling_rgcn_training_amd.plan import clear_plan_cache
+    n, d = x.shape
+    e = int(et.shape[0])
+    r = int(weight.shape[0])
+    rows = []
+    for pieces in pieces_list:
+        for exch in exchanges:
+            conv = RGCNConv(d, d, r).to(dev)
+            conv.path = "ring"
+            with torch.no_grad():
+                conv.weight.copy_(weight)
+                conv.root.copy_(root)
+            rdist.attach(conv, n, e, edge_index=ei, pieces=pieces, exchange=exch, emulate=(world, 0))
+            bc = getattr(conv.dist, "block_costs", None)
+            heaviest = int(bc.sum(0).argmax()) if bc is not None else 0
+            todo = ranks if ranks is not None else sorted({0, heaviest})
+            for rk in todo:
+                rdist.attach(conv, n, e, edge_index=ei, pieces=pieces, exchange=exch, emulate=(world, rk))
+                dctx = conv.dist
+                xx = x.detach().requires_grad_(True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                plans = conv._plans(xx, ei, et)
+                torch.cuda.synchronize()
+                plan_s = time.perf_counter() - t0
+                evs = []
+                for i in range(warmup + steps):
+                    xx.grad = None
+                    conv.zero_grad(set_to_none=True)
+                    a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    a.record()
+                    out = conv(xx, ei, et)
+                    b.record()
+                    out.backward(dg)
+                    c.record()
+                    if i >= warmup:
+                        evs.append((a, b, c))
+                torch.cuda.synchronize()
+                f_ms = statistics.median(a.elapsed_time(b) for a, b, c in evs)
+                b_ms = statistics.median(b.elapsed_time(c) for a, b, c in evs)
+                own_rows = sum(dctx.node_range(s_, n)[1] - dctx.node_range(s_, n)[0] for s_ in range(dctx.pieces))
+                row = {"world": world, "pieces": dctx.pieces, "exchange": exch, "rank": rk, "heaviest_rank": heaviest,
+                       "rank_share_ms": f_ms + b_ms, "forward_ms": f_ms, "backward_ms": b_ms,
+                       "single_gpu_step_over_world_ms": single_step_ms / world,
+                       "share_over_ideal": (f_ms + b_ms) / (single_step_ms / world),
+                       "owned_rows": own_rows, "owned_edges_in": sum(p.fwd.n_edges for p in plans.pieces if p.fwd is not None),
+                       "plan_build_s": plan_s}
+                remote = n - own_rows
+                if exch == "needed":
+                    nf, nb = plans.needed_fwd, plans.needed_bwd
+                    row["rows_needed_fraction"] = {"forward_output": nf.rows_needed / max(1, nf.rows_remote),
+                                                   "dx_output": nb.rows_needed / max(1, nb.rows_remote)}
+                    recv_rows = (nf.rows_needed + nb.rows_needed) / 2
+                else:
+                    recv_rows = remote
+                ld = (d + 3) // 4 * 4
+                per_link = recv_rows * ld * 4 / max(1, world - 1)
+                pred = {}
+                for name, rate in (("153_GBps", 153e9), ("76_GBps", 76e9)):
+                    c_ms = per_link / rate * 1e3
+                    p_ = dctx.pieces
+                    t_f = max(f_ms + c_ms / p_, f_ms / p_ + c_ms)
+                    t_b = max(b_ms, f_ms / p_ + c_ms)
+                    pred[name] = {"ms_per_gather_on_the_wire": c_ms, "step_ms": t_f + t_b, "speedup_over_1_gpu": single_step_ms / (t_f + t_b)}
+                row["bytes_per_link_per_gather"] = per_link
+                row["predicted"] = pred
+                rows.append(row)
+                log(f"emulated rank {rk}/{world}, pieces {dctx.pieces}, exchange {exch}: fwd {f_ms:.3f} + bwd {b_ms:.3f} = {f_ms + b_ms:.3f} ms "
+                    f"(step / {world} = {single_step_ms / world:.3f}); predicted {pred['153_GBps']['speedup_over_1_gpu']:.2f}x at 153 GB/s per link, "
+                    f"{pred['76_GBps']['speedup_over_1_gpu']:.2f}x at 76")
+                del plans, out, xx
+                clear_plan_cache()
+            del conv
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +323,14 @@ def main():
                          "under the kernels of piece s + 1, the exposed tail is 1 / pieces of a gather")
     ap.add_argument("--balance", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: cut the node ranges by edge count (auto: only where equal node blocks differ by more than 5 %%)")
+    ap.add_argument("--exchange", choices=["full", "needed"], default="full",
+                    help="N > 1: 'needed' = a rank receives only the rows its plans read (all_to_all_single with split sizes, opt-in: "
+                         "unread rows of the layer's output are not written); 'full' = the in-place all-gather")
+    ap.add_argument("--emulate-world", type=int, default=8,
+                    help="N = 1: after the headline run, ONE GPU stands in for a rank of a world of this size (no collectives): "
+                         "rank_share_ms per pieces / exchange, 0 = skip")
+    ap.add_argument("--emulate-rank", type=int, default=None, help="which rank to emulate (default: rank 0 and the heaviest rank of the cut)")
+    ap.add_argument("--emulate-only", action="store_true", help="skip the ladder, the CPU baseline and the alt-kernel leg")
     args = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -271,7 +368,7 @@ def main():
     del weight, root
     if world > 1:
         rdist.attach(conv, n, e, edge_index=ei, pieces=args.pieces or rdist.PIECES,
-                     balance={"auto": None, "on": True, "off": False}[args.balance])
+                     balance={"auto": None, "on": True, "off": False}[args.balance], exchange=args.exchange)
     x.requires_grad_(True)
 
     torch.cuda.synchronize()
@@ -337,7 +434,12 @@ def main():
         bc = getattr(dctx, "block_costs", None)
         rank_rows = bc.sum(0) if bc is not None else None        # rows (in- + out-edges + root rows) every rank walks per step
         gather_bytes = n * d * 4 * (world - 1) / world             # what one gather moves INTO a rank
+        nf_, nb_ = getattr(plans, "needed_fwd", None), getattr(plans, "needed_bwd", None)
         comm = {"backend": backend, "pieces": dctx.pieces, "cut": "uniform" if dctx.uniform else "balanced by edge count",
+                "exchange": dctx.exchange,
+                # exchange = "needed": the share of the rows other ranks own that this rank's plans read at all (rank 0)
+                "rows_needed_fraction": None if nf_ is None else {"forward_output": nf_.rows_needed / max(1, nf_.rows_remote),
+                                                                  "dx_output": nb_.rows_needed / max(1, nb_.rows_remote)},
                 "rows_walked_per_rank": None if rank_rows is None else {
                     "max": float(rank_rows.max()), "mean": float(rank_rows.mean()), "max_over_mean": float(rank_rows.max() / rank_rows.mean()),
                     "per_block_max_over_mean": float(bc.max() / bc.mean())},
@@ -480,6 +582,8 @@ def main():
     # (rgcn_tile_kernel) when the default producer-split bf16 x 3 kernel ran above, and vice versa -- on the same box right
     # after the main run, with its own plans
     alt = None
+    if args.emulate_only:
+        args.no_ladder = args.no_cpu_baseline = True
     if world == 1 and (n, e, r, d) == HEADLINE and not args.no_ladder:
         main_mode = conv.split_producers
         try:
@@ -525,6 +629,14 @@ def main():
             log(f"alt leg skipped: {err!r}")
         finally:
             conv.split_producers = main_mode
+    emu = None
+    if world == 1 and args.emulate_world > 1:
+        try:
+            emu = emulate_world(conv.weight.detach(), conv.root.detach(), ei, et, x.detach(), dg, dev, args.emulate_world,
+                                statistics.median(step_ms), ranks=None if args.emulate_rank is None else [args.emulate_rank],
+                                pieces_list=(args.pieces,) if args.pieces else (1, 2, 4))
+        except Exception as err:      # (a secondary leg must not take the headline record down)
+            log(f"emulate-world leg skipped: {err!r}")
     if rank == 0:
         rec = {
             "metric": "edges/s per RGCN layer (fwd+bwd)",
@@ -553,6 +665,10 @@ def main():
             "plan_build_s": plan_s,
             "plan_bytes": sum(p.nbytes() for p in fps + bps),
         }
+        if emu is not None:
+            # one GPU standing in for one rank of the 8-GPU job: what a rank's share of the step costs (measured), what its
+            # exchanges would move, and the step time / speed-up those two predict at a given link rate (see emulate_world)
+            rec["emulated_world"] = emu
         if comm is not None:
             rec["comm"] = comm
     # ---- the smaller rungs and the CPU baseline beside its rung (N = 1 only) ----------------------------------------
@@ -563,17 +679,21 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_ladder:
             ladder = [{"rung": "10M/100M", "nodes": n, "edges": e, "relations": r, "in": d, "out": d,
-                       "gpu_ms_per_step": rec["ms_per_step_median"], "gpu_edges_per_s": e / (rec["ms_per_step_median"] * 1e-3)}]
+                       "gpu_ms_per_step": rec["ms_per_step_median"], "gpu_edges_per_s": e / (rec["ms_per_step_median"] * 1e-3),
+                       "roofline_step": {k: rec["roofline_step"][k] for k in ("bound", "algorithmic_bytes_per_step", "achieved", "peak", "unit", "frac")}}]
             for name, ln, le, lr, lin, lout, nb in LADDER:
                 skew = "skew" in name
                 ms, ps_, msg, st = gpu_rung(ln, le, lr, lin, lout, dev, graph=le <= 1_000_000, num_bases=nb, skew=skew,
                                             steps=10 if skew else 20, warmup=3 if skew else 5)
                 ladder.append({"rung": name, "nodes": ln, "edges": le, "relations": lr, "in": lin, "out": lout,
                                "gpu_ms_per_step": ms, "gpu_edges_per_s": le / (ms * 1e-3), "plan_build_s": ps_, "plan": st})
-                if skew:      # its own step-level roofline: the same algorithmic bytes as the uniform graph of that size
-                    sb = sum(algorithmic_bytes(le, ln, lr, lin, lout).values())
-                    ladder[-1]["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": sb, "achieved": sb / (ms * 1e-3) / 1e9,
-                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                # every rung's own step-level roofline: SURVEY.md 8d bytes for its N / E / R' / widths (the skew rung: the same
+                # algorithmic bytes as the uniform graph of that size) over the eager step and, where one was taken, the replayed one
+                sb = sum(algorithmic_bytes(le, ln, lr, lin, lout).values())
+                ladder[-1]["roofline_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": sb, "achieved": sb / (ms * 1e-3) / 1e9,
+                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if msg is not None:
+                    ladder[-1]["roofline_step"]["frac_hipgraph_replay"] = sb / (msg * 1e-3) / 1e9 / HBM_PEAK_GBS
                 if nb is not None:
                     ladder[-1]["num_bases"] = nb
                 if msg is not None:

@@ -317,8 +317,10 @@ def edge_weights(graph: RgcnGraphStruct, aggr: str, ws: torch.Tensor) -> torch.T
 
 def plan_build(graph: RgcnGraphStruct, w: torch.Tensor, transposed: bool, node_begin: int, node_end: int, tile: int,
                chunk: int, ws: torch.Tensor, split=False):
-    """-> (RgcnPlanStruct, dict of the ten device arrays, n_edges placed).  split: plan layout (False / True = 0 / 1; 2 =
-    relation-major units of the edge-parallel path)"""
+    """-> (RgcnPlanStruct, dict of the ten device arrays, n_edges placed).  split: plan layout -- 0 (False) rows of a (tile, relation) group dealt
+    over its row tiles; 1 (True) the team placement of experiment builds; 2 relation-major units of the
+    edge-parallel path (one pseudo tile); 3 layout 0 with the rows of a (destination, relation) run compacted onto one head slot
+    (compact_runs_kernel: only rgcn_tile3p_kernel walks it, every weight-gradient entry point refuses it)"""
     lib, dev = load(), ws.device
     sizes = RgcnPlanSizes()
     with torch.cuda.device(dev):

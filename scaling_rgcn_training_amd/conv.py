@@ -1,7 +1,7 @@
 """``RGCNConv``: constructor-, attribute- and forward-compatible with PyG 2.3.1
 ``torch_geometric.nn.RGCNConv`` as the reference uses it (/root/reference/model/layers.py:15-16,
 21-23, 33-46), with forward and backward running as the HIP kernels of
-``csrc/rgcn_kernels.hip`` through the C ABI of ``include/rgcn_mi355x.h``.
+``csrc/rgcn_tile_fp32*.hip`` / ``rgcn_tile3p.hip`` / ``rgcn_ep.hip`` / ``rgcn_dw_*.hip`` through the C ABI of ``include/rgcn_mi355x.h``.
 
 Mutability contract (model/layers.py:33-46, model/modelTrainer.py:26-39): ``weight`` / ``root`` /
 ``bias`` are plain ``nn.Parameter`` attributes that callers REPLACE after construction and may
@@ -91,11 +91,27 @@ class DistContext:
         ``all_gather_into_tensor`` per piece -- the default wherever equal node blocks hold equal edge counts within 5 %;
       * balanced (``dist.balanced_bounds``: blocks of about equal EDGE count): unequal blocks, gathered by one
         broadcast per rank and piece (what an uneven all-gather is underneath).
+    Two exchanges (round 4):
+      * ``exchange = "full"`` (default): every rank ends up with every row of the gathered matrix -- the per-layer all-reduce
+        of north_star with one contributor per row;
+      * ``exchange = "needed"`` (opt-in, dist.attach(..., exchange="needed")): a rank receives only the rows its own plans
+        gather (dist.NeededRows, derived from the edge list at plan time: the sources of the edges into its blocks for a
+        forward output, the destinations of the edges out of them for a dX output) -- one ``all_to_all_single`` with split sizes
+        per piece instead of the all-gather, packed rows scattered into place.  Owned rows and read rows are bit-identical to
+        the full exchange; rows no plan of this rank reads are NOT written (they hold whatever the allocator returned), so
+        the mode is for layers whose output feeds another partitioned layer over the same graph, not for a model's last layer.
+    ``emulate``: no process group at all -- ONE process stands in for rank ``rank`` of a ``world``-rank job: it builds that
+    rank's plans, launches that rank's kernels, packs / unpacks that rank's rows, and skips the collectives (bench.py
+    --emulate-world: what a rank's share of a step costs, measured on one GPU).
     ``stats`` counts what the collectives moved (bench.py reports it per step)."""
 
-    def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int, bounds=None):
+    def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int, bounds=None, exchange: str = "full",
+                 emulate: bool = False):
+        if exchange not in ("full", "needed"):
+            raise ValueError("exchange must be 'full' or 'needed'")
         self.group, self.rank, self.world = group, rank, world
         self.pieces = pieces
+        self.exchange, self.emulate = exchange, emulate
         self.uniform = bounds is None
         self.piece_rows = piece_rows if self.uniform else None
         self.bounds = [i * piece_rows for i in range(pieces * world + 1)] if self.uniform else [int(b) for b in bounds]
@@ -128,15 +144,31 @@ class DistContext:
 
 
 def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, device,
-                   dtype: torch.dtype = torch.float32) -> Tensor:
-    """Run ``launch(plan, out_rows)`` for every piece this rank owns and gather the pieces, overlapping the collective of
-    piece s (RCCL's own stream) with the kernels of piece s + 1 (current stream).  Uniform cut: an IN-PLACE all-gather (this
-    rank's block is already where the collective would put it: sendbuf == recvbuf + rank * count, the aliasing NCCL / RCCL
-    document for in-place all-gather).  Balanced cut: every rank broadcasts its block of the piece in place."""
+                   dtype: torch.dtype = torch.float32, needed=None, defer: bool = False):
+    """Run ``launch(plan, out_rows)`` for every piece this rank owns and exchange the pieces, overlapping the collective of
+    piece s (RCCL's own stream) with the kernels of piece s + 1 (current stream).
+    Full exchange, uniform cut: an IN-PLACE all-gather (this rank's block is already where the collective would put it:
+    sendbuf == recvbuf + rank * count, the aliasing NCCL / RCCL document for in-place all-gather).  Balanced cut: every rank
+    broadcasts its block of the piece in place.  ``needed`` (dist.NeededRows of this direction, exchange = "needed"): the rows
+    the peers read of this rank's block are packed (index_select, peer by peer), travel in one all_to_all_single with split
+    sizes, and the rows this rank reads of the peers' blocks are scattered into place (index_copy_) one piece behind the
+    launches.  Returns the gathered matrix, or with ``defer`` (the backward: the weight-gradient kernels need none of the
+    gathered rows and run under the dX exchange) a pair (matrix, finish) -- ``finish()`` makes the current stream wait for what
+    is still in flight."""
     full = torch.empty(max(dctx.total_rows, n), ld, dtype=dtype, device=device)
+    if getattr(dctx, "poison_unread", False):      # tests: a row no exchange wrote is a NaN wherever it is read
+        full.fill_(float("nan"))
     handles = []
     w = dctx.world
     esz = full.element_size()
+    live = not dctx.emulate
+
+    def unpack(s_idx, hs, recv):
+        for h in hs:
+            h.wait()
+        if recv is not None and recv.shape[0] > 0:
+            full.index_copy_(0, needed.recv_idx[s_idx], recv)
+
     for s_idx, plan in enumerate(plans_list):
         b, e = dctx.block(s_idx)
         mine = full[b:e]
@@ -144,34 +176,54 @@ def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, dev
             launch(plan, mine)
         if plan.n_owned < e - b:
             mine[plan.n_owned:].zero_()     # rows past the graph's end: defined bytes on the wire
-        hs = []
-        if dctx.uniform:
+        hs, recv = [], None
+        if needed is not None:
+            send = full.index_select(0, needed.send_idx[s_idx])
+            recv = torch.empty(int(needed.recv_idx[s_idx].shape[0]), ld, dtype=dtype, device=device)
+            if live:
+                hs.append(torch.distributed.all_to_all_single(recv, send, needed.recv_splits[s_idx], needed.send_splits[s_idx],
+                                                              group=dctx.group, async_op=True))
+            dctx.stats["all_gather_bytes"] += recv.shape[0] * ld * esz
+        elif dctx.uniform:
             sup = full[dctx.bounds[s_idx * w]:dctx.bounds[(s_idx + 1) * w]]
-            hs.append(torch.distributed.all_gather_into_tensor(sup, mine, group=dctx.group, async_op=True))
+            if live:
+                hs.append(torch.distributed.all_gather_into_tensor(sup, mine, group=dctx.group, async_op=True))
             dctx.stats["all_gather_bytes"] += (w - 1) * (e - b) * ld * esz      # bytes this rank RECEIVES
         else:
             for r in range(w):
                 rb, re = dctx.block(s_idx, r)
                 if re > rb:
-                    hs.append(torch.distributed.broadcast(full[rb:re], src=dctx.src_rank(r), group=dctx.group, async_op=True))
+                    if live:
+                        hs.append(torch.distributed.broadcast(full[rb:re], src=dctx.src_rank(r), group=dctx.group, async_op=True))
                     if r != dctx.rank:
                         dctx.stats["all_gather_bytes"] += (re - rb) * ld * esz
-        handles.append(hs)
+        handles.append((s_idx, hs, recv))
         dctx.stats["all_gather"] += 1
-    timed = dctx.time_waits and device.type == "cuda"
-    evs = []
-    for hs in handles:          # piece by piece: which piece's gather the launch stream had to wait for
+        if needed is not None and len(handles) >= 2 and handles[-2] is not None:
+            # the packed rows of the piece before: their collective had this piece's kernels to finish under
+            unpack(*handles[-2])
+            handles[-2] = None
+
+    def finish():
+        timed = dctx.time_waits and device.type == "cuda"
+        evs = []
+        for item in handles:          # piece by piece: which piece's exchange the launch stream had to wait for
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if item is not None:
+                unpack(*item)
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                evs.append((e0, e1))
         if timed:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        for h in hs:
-            h.wait()
-        if timed:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            evs.append((e0, e1))
-    if timed:
-        dctx.stats["wait_events"].append(evs)
+            dctx.stats["wait_events"].append(evs)
+        handles.clear()
+
+    if defer:
+        return full[:n], finish
+    finish()
     return full[:n]
 
 
@@ -213,7 +265,8 @@ class _RGCNLayerFn(torch.autograd.Function):
                     _lib.fwd(_lib.plan_struct(pl), xp, din, packed, bs, rows, dout, act, flags)
                 else:
                     _lib.ep_layer(pl, xp, din, packed, bs, rows, dout, act, None, flags)
-            out = _gather_pieces(dctx, [p.fwd if p.fwd is not None else p.ep_fwd for p in plans.pieces], launch_fwd, ldo, n, x.device)
+            out = _gather_pieces(dctx, [p.fwd if p.fwd is not None else p.ep_fwd for p in plans.pieces], launch_fwd, ldo, n, x.device,
+                                 needed=plans.needed_fwd if dctx.exchange == "needed" else None)
         ctx.plans, ctx.dctx = plans, dctx
         ctx.dims = (n, din, dout, num_rel)
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
@@ -238,6 +291,7 @@ class _RGCNLayerFn(torch.autograd.Function):
         if ctx.need_a:
             gp = _lib.act_backward(a_out, gp, ctx.act)       # dL/dz = dL/da * act'(a)
         dx = dw = droot = dbias = None
+        finish_dx = None
         need_root = need_root and ctx.has_root
         need_bias = need_bias and ctx.has_bias
         dev = g.device
@@ -288,7 +342,10 @@ class _RGCNLayerFn(torch.autograd.Function):
                         _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din, m, flags)
                     else:
                         _lib.ep_layer(pl, gp, dout, packed_t, None, rows, din, _lib.ACT_NONE, m, flags)
-                dxp = _gather_pieces(dctx, [p.bwd if p.bwd is not None else p.ep_bwd for p in plans.pieces], launch_dx, ldx, n, dev)
+                # the exchange of the dX pieces stays in flight under the weight-gradient kernels below (they read x and the
+                # rank's own rows of g, none of the gathered rows); finish_dx() is the wait
+                dxp, finish_dx = _gather_pieces(dctx, [p.bwd if p.bwd is not None else p.ep_bwd for p in plans.pieces], launch_dx, ldx, n, dev,
+                                                needed=plans.needed_bwd if dctx.exchange == "needed" else None, defer=True)
             dx = dxp if ldx == din else dxp[:, :din]
         if tiles_path:
             # relations: tile-major kernel (gradient rows staged in LDS)
@@ -332,10 +389,13 @@ class _RGCNLayerFn(torch.autograd.Function):
             if acc is None:
                 acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
             if dctx is not None:
-                torch.distributed.all_reduce(acc, group=dctx.group)
+                if not dctx.emulate:
+                    torch.distributed.all_reduce(acc, group=dctx.group)
                 dctx.stats["all_reduce"] += 1
                 dctx.stats["all_reduce_bytes"] += acc.numel() * 4
             dw, droot, dbias = views(acc)
+        if finish_dx is not None:
+            finish_dx()
         dcomp = None
         if decomposed and dw is not None:
             dw, dcomp = _lib.decomposed_weight_grads(dw.contiguous(), wf, cp, need_wparam, need_comp)
@@ -529,11 +589,9 @@ class RGCNConv(nn.Module):
             raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
         plans = self._plans(x, edge_index, edge_type)
         flags = self.kernel_flags
-        if self.dist is None:
-            first = plans.fwd if plans.fwd is not None else plans.bwd
-        else:
-            first = next((q for pc in plans.pieces for q in (pc.fwd, pc.bwd) if q is not None), None)
-        if self._use_split_producers(first.chunk if first is not None else 128):
+        # (the arithmetic mode follows the layer and the graph's size -- the chunk of self.layout -- not which path the other
+        # direction happened to take: an edge-parallel pair on a graph too small for 128-slot chunks stays on exact fp32)
+        if self._use_split_producers(self.layout(x.shape[0], int(edge_type.shape[0]))[1]):
             # rgcn_fwd / rgcn_bwd_dx / rgcn_bwd_dw_tiles / rgcn_ep_transform: the bf16 x 3 (fp32-equivalent) forms of 64 x 64 layers;
             # the library falls back where they do not fit
             flags |= _lib.FLAG_SPLIT_PRODUCERS

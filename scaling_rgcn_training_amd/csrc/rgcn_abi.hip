@@ -203,7 +203,7 @@ extern "C" const char* rgcn_status_string(int status) {
 
 extern "C" int rgcn_padded_width(int width) { return padded_width(width); }
 
-// 64 x 64 layers also carry the bf16 x 3 split of the weights (rgcn_tile3_kernel), behind the fp32 fragments
+// 64 x 64 layers also carry the bf16 x 3 split of the weights (rgcn_tile3p_kernel, rgcn_ep_transform3_kernel), behind the fp32 fragments
 static size_t pack3_floats(int num_relations, int KP, int NP) {
     return (KP == 64 && NP == 64) ? (size_t)(num_relations + 1) * kPack3FloatsPerRel : 0;
 }

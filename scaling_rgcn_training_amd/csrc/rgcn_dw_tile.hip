@@ -68,6 +68,28 @@ __device__ __forceinline__ unsigned dw_stamp() {
 constexpr int kDwTileT = 320;                    // gradient rows per LDS buffer = tile size of the plan this kernel walks
 constexpr int kDwTileWalkers = 64;               // tile ranges; x 4 relation quarters = 256 workgroups, one per CU
 constexpr int kDwTileMaxRel = 32;
+// Split form only: a wave folds its 64 x 64 accumulator into its own fp32 slab every kDwFlushUnits units (vector adds: round to
+// nearest) and starts the next period from zero, with the SIGN of the period's products flipped (the weight of every slot times
+// -1 on odd periods; the fold subtracts those).  Why: v_mfma_f32_16x16x32_bf16 aligns every product to the accumulator's exponent
+// and TRUNCATES it there -- an error of one sign, proportional to ulp(accumulator), that a long-lived accumulator turns into a
+// bias growing with the rows per slab (-7.5e-2 on d_weight at 12M edges per relation, profiles/r03b_*).  A period of 64 units
+// (~3.5K rows) keeps ulp(accumulator) ~60x smaller than a whole launch's; alternating signs make consecutive periods' biases
+// cancel instead of add.  The slab is private to the wave: no atomics, the same sum order every run.  16 KiB read + written per
+// fold = 0.5 MiB per wave and launch at the headline config (17 folds), ~1 GB per launch against 29.8.
+#ifndef RGCN_DW_FLUSH_UNITS
+#define RGCN_DW_FLUSH_UNITS 64
+#endif
+#ifndef RGCN_DW_FLUSH_SIGNS
+#define RGCN_DW_FLUSH_SIGNS 1
+#endif
+// 1: the fold as 64 no-return global_atomic_add_f32 per lane instead of 16 x (load 16 B, add, store 16 B): nothing to wait for
+// (the read-modify-write form drains the wave's prefetch queue in front of every fold: +1.6 % per launch at 64 units, A/B below).
+// Still deterministic: the slab is private to the wave, atomics of one wave to one address retire in issue order, and the
+// add at the L2 atomic unit rounds to nearest like v_add_f32.
+#ifndef RGCN_DW_FOLD_ATOMIC
+#define RGCN_DW_FOLD_ATOMIC 0
+#endif
+constexpr int kDwFlushUnits = RGCN_DW_FLUSH_UNITS;      // 0: one accumulator for the whole launch (round 2 / 3)
 
 struct DwTileArgs {
     const int* rel_order;   // of a plan with tile = kDwTileT, 64-slot chunks (unit == chunk), layout 0
@@ -211,7 +233,7 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     };
     // half a unit as ONE 32-row k-step (a half with no valid slot is skipped; padding slots inside one have weight 0)
     auto compute_half3 = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {
-        if (2 * h >= ngrp) return;
+        if (2 * h >= ngrp) return;      // (ix.w carries the period's sign, see fold_into_slab)
         const unsigned loc = (unsigned)(ix.g - tile_row0);
         const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));
         float wv[HS];
@@ -366,6 +388,37 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     // MFMAs, not at the top of the iteration; sched_barrier only binds the scheduler inside a block).  A compiler-level memory
     // clobber after each batch keeps the loads where issue_half puts them: a read cannot be moved across it.
     auto pin_loads = [] { asm volatile("" ::: "memory"); };
+    // slab += sgn * acc, acc = 0 (split form; the slab was cleared by the host-side memset)
+    float* const slab = a.slabs + ((size_t)p * a.num_rel + (have ? rel : 0)) * (64 * 64);
+    auto fold_into_slab = [&](float sgn) {
+        if (!have) return;
+#if RGCN_DW_FOLD_ATOMIC
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    unsafeAtomicAdd(slab + (4 * (4 * kq + r) + ia) * NP + 4 * ml + jb, sgn * acc[ia][jb][r]);
+                    acc[ia][jb][r] = 0.f;
+                }
+        return;
+#endif
+#pragma unroll
+        for (int ia = 0; ia < 4; ++ia)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4* q = (f32x4*)(slab + (4 * (4 * kq + r) + ia) * NP + 4 * ml);
+                f32x4 v = *q;
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    v[jb] += sgn * acc[ia][jb][r];
+                    acc[ia][jb][r] = 0.f;
+                }
+                *q = v;
+            }
+    };
+    float sgn = 1.f;
     dma_tile(t0, 0);
     int k = 0;
     int uid_cur = unit_of(0), uid_nxt = unit_of(1), uid_nn = unit_of(2);
@@ -411,6 +464,7 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             pin_loads();
             __builtin_amdgcn_sched_barrier(0);
             DWS(1)               // second half's rows issued
+            if constexpr (SPLIT && kDwFlushUnits > 0 && RGCN_DW_FLUSH_SIGNS) ix_cur.w *= sgn;
             if constexpr (SPLIT) compute_half3(s0, ix_cur, 0, ngrp, gbuf, t * T);
             else compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
@@ -423,6 +477,12 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             else compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             ++k;
+            if constexpr (SPLIT && kDwFlushUnits > 0) {
+                if (k % (kDwFlushUnits > 0 ? kDwFlushUnits : 1) == 0) {      // wave-uniform: k counts this wave's units
+                    fold_into_slab(sgn);
+                    if (RGCN_DW_FLUSH_SIGNS) sgn = -sgn;
+                }
+            }
             ix_cur = ix_nxt;
             ix_nxt = ix_nn;
             uid_cur = uid_nxt;
@@ -450,8 +510,11 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the accumulators are read by plain stores the compiler schedules: keep them clear of the last asm MFMA
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if constexpr (SPLIT && kDwFlushUnits > 0) {
+        fold_into_slab(sgn);
+        return;
+    }
     if (have) {
-        float* slab = a.slabs + ((size_t)p * a.num_rel + rel) * (64 * 64);
 #pragma unroll
         for (int ia = 0; ia < 4; ++ia)
 #pragma unroll

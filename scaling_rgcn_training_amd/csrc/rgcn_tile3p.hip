@@ -9,7 +9,7 @@
 //     v_mfma_f32_16x16x32_bf16: 24 significant bits on both operands, i.e. fp32-equivalent (error against float64 no larger
 //     than the sequential fp32 chain's), for 2.7x fewer cycles of the SIMD's arithmetic pipe than v_mfma_f32_16x16x4_f32;
 //   * the 3-way split of x (5.5 vector instructions per element) is what killed that gain when the CONSUMERS did it per
-//     row tile and per wave (rgcn_tile3_kernel).  Here the producers gather rows into REGISTERS (buffer loads, two chunks
+//     row tile and per wave (the consumer-split kernel of round 2, deleted in round 3: DESIGN.md 4.6).  Here the producers gather rows into REGISTERS (buffer loads, two chunks
 //     ahead), split them once and write three bf16 planes into the ring; their vector work overlaps the consumers' bf16
 //     MFMAs on the shared SIMD (tools/probes/mfma_cross_wave_overlap.hip: a VALU wave slows 1.3x beside bf16 MFMAs, the
 //     MFMA wave not at all).  W is split at pack time (rgcn_pack3_kernel's planes, already part of the packed weights).

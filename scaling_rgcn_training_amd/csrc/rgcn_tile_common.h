@@ -1,5 +1,5 @@
 // rgcn_tile_common.h -- what the forward / dX kernels of the library share: launch arguments, the accumulator tile's row
-// stride and the tile epilogue (store + fused activation / ReLU mask).  Included by rgcn_kernels.hip (exact-fp32 kernel,
+// stride and the tile epilogue (store + fused activation / ReLU mask).  Included by rgcn_tile_fp32_kernel.h (exact-fp32 kernel,
 // consumer-split bf16 kernel) and rgcn_tile3p.hip (producer-split bf16 kernel).
 #pragma once
 #include "rgcn_common.h"

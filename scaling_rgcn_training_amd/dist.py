@@ -46,9 +46,10 @@ def tile_costs(edge_index: Tensor, n_nodes: int, tile: int) -> Tensor:
 
 
 def block_costs(costs: Tensor, bounds, tile: int) -> Tensor:
-    """cost of every block of a cut (bounds in nodes, tile-aligned)"""
+    """cost of every block of a cut (bounds in nodes; every bound is a tile multiple except a cut's last one, the graph's
+    end, which closes a partial tile: rounded UP, so that the last tile's cost counts)"""
     cum = torch.cat([torch.zeros(1, dtype=torch.float64), torch.cumsum(costs, 0)])
-    t = torch.clamp(torch.tensor([b // tile for b in bounds]), max=costs.numel())
+    t = torch.clamp(torch.tensor([(b + tile - 1) // tile for b in bounds]), max=costs.numel())
     return cum[t[1:]] - cum[t[:-1]]
 
 
@@ -69,34 +70,93 @@ def balanced_bounds(costs: Tensor, n_nodes: int, tile: int, world: int, pieces: 
 
 
 def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge_index: Optional[Tensor] = None,
-                 balance: Optional[bool] = None) -> Optional[DistContext]:
+                 balance: Optional[bool] = None, exchange: str = "full", emulate=None) -> Optional[DistContext]:
     """edge_index given: keep the uniform cut (one in-place all-gather per piece) while its blocks' edge counts stay within
-    BALANCE_TOLERANCE of their mean, else cut by edge count (``balance`` True / False pins the choice)."""
-    if not dist.is_available() or not dist.is_initialized():
-        return None
-    world = dist.get_world_size(group)
+    BALANCE_TOLERANCE of their mean, else cut by edge count (``balance`` True / False pins the choice).
+    ``exchange``: "full" | "needed" (conv.DistContext).  ``emulate = (world, rank)``: no process group -- the context of rank
+    ``rank`` of a ``world``-rank job in THIS process, collectives skipped (bench.py --emulate-world)."""
+    if emulate is not None:
+        world, rank = int(emulate[0]), int(emulate[1])
+        assert 0 <= rank < world
+    else:
+        if not dist.is_available() or not dist.is_initialized():
+            return None
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
     if world == 1:
         return None
     n_tiles = (n_nodes + tile - 1) // tile
     pieces = max(1, min(pieces, n_tiles // world if n_tiles >= world else 1))
     pr = piece_rows(n_nodes, tile, world, pieces)
-    ctx = DistContext(group, dist.get_rank(group), world, pr, pieces)
+    kw = {"exchange": exchange, "emulate": emulate is not None}
+    ctx = DistContext(group, rank, world, pr, pieces, **kw)
     if edge_index is not None and balance is not False:
         costs = tile_costs(edge_index, n_nodes, tile)
         bc = block_costs(costs, ctx.bounds, tile)
-        if balance or float(bc.max()) > (1.0 + BALANCE_TOLERANCE) * float(bc.mean()):
-            ctx = DistContext(group, dist.get_rank(group), world, 0, pieces, balanced_bounds(costs, n_nodes, tile, world, pieces))
+        # (the uniform cut pads its last blocks past the graph's end: compare the heaviest block with a block's share of the
+        # total, not with a mean the empty trailing blocks pull down)
+        if balance or float(bc.max()) > (1.0 + BALANCE_TOLERANCE) * float(costs.sum()) / (pieces * world):
+            ctx = DistContext(group, rank, world, 0, pieces, balanced_bounds(costs, n_nodes, tile, world, pieces), **kw)
             bc = block_costs(costs, ctx.bounds, tile)
         ctx.block_costs = bc.view(pieces, world)
     return ctx
 
 
+class NeededRows:
+    """exchange = "needed", one direction (forward outputs or dX outputs) of one rank.  Per piece s:
+    ``send_idx[s]``    int64 row ids of THIS rank's block s that some peer reads, peer after peer (rank order), ascending inside a peer;
+    ``send_splits[s]`` rows per peer (0 for this rank itself);
+    ``recv_idx[s]``    int64 row ids of the PEERS' blocks s that this rank reads, peer after peer, ascending;
+    ``recv_splits[s]`` rows per peer.
+    ``rows_needed`` / ``rows_remote``: how many of the rows other ranks own this rank reads at all (bench.py: rows_needed_fraction)."""
+
+    def __init__(self, send_idx, send_splits, recv_idx, recv_splits, rows_needed: int, rows_remote: int):
+        self.send_idx, self.send_splits, self.recv_idx, self.recv_splits = send_idx, send_splits, recv_idx, recv_splits
+        self.rows_needed, self.rows_remote = rows_needed, rows_remote
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * 8 for t in self.send_idx + self.recv_idx)
+
+
+def needed_rows(edge_index: Tensor, n_nodes: int, dctx: DistContext):
+    """(forward, transposed) NeededRows of rank ``dctx.rank``, from the replicated edge list alone -- every rank derives its own
+    receive lists AND what every peer will ask of it, so no plan-time communication and every pair of ranks agrees by
+    construction.  A plan of rank c gathers, in the forward direction, the rows ``src(e)`` of the edges with ``dst(e)`` in c's
+    blocks (the root pseudo edges read c's own rows); the transposed plans gather ``dst(e)`` of the edges with ``src(e)`` in c's
+    blocks.  One [world, N] boolean table per direction (80 MB at 10M nodes, world 8), filled by one scatter."""
+    dev = edge_index.device
+    w, me = dctx.world, dctx.rank
+    cuts = torch.tensor(dctx.bounds[1:], dtype=torch.int64, device=dev)
+    nodes = torch.arange(n_nodes, device=dev)
+    owner = torch.searchsorted(cuts, nodes, right=True) % w       # the rank that owns every node
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    out = []
+    for consumer_of, row in ((dst, src), (src, dst)):
+        need = torch.zeros(w, n_nodes, dtype=torch.bool, device=dev)
+        need[owner[consumer_of], row] = True
+        need[owner, nodes] = False          # a rank's own rows never travel
+        send_idx, send_splits, recv_idx, recv_splits = [], [], [], []
+        for s in range(dctx.pieces):
+            b, e = dctx.node_range(s, n_nodes)
+            parts = [torch.nonzero(need[c, b:e]).squeeze(1) + b for c in range(w)]
+            send_idx.append(torch.cat(parts))
+            send_splits.append([int(p.numel()) for p in parts])
+            parts = []
+            for q in range(w):
+                qb, qe = dctx.node_range(s, n_nodes, q)
+                parts.append(torch.nonzero(need[me, qb:qe]).squeeze(1) + qb)
+            recv_idx.append(torch.cat(parts))
+            recv_splits.append([int(p.numel()) for p in parts])
+        out.append(NeededRows(send_idx, send_splits, recv_idx, recv_splits, int(need[me].sum()), int((owner != me).sum())))
+    return out[0], out[1]
+
+
 class RankPlans:
     """The graph plans of one rank: one forward / transposed pair per owned block (piece)."""
 
-    def __init__(self, pieces):
+    def __init__(self, pieces, needed_fwd: Optional[NeededRows] = None, needed_bwd: Optional[NeededRows] = None):
         self.pieces = pieces
         self.num_edges = sum(p.num_edges for p in pieces)
+        self.needed_fwd, self.needed_bwd = needed_fwd, needed_bwd      # exchange = "needed" (conv._gather_pieces)
 
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
@@ -106,10 +166,11 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
     laid out from the same edge list: on the GPU by the library's plan builder with the piece's node range (it keeps
     the edges that scatter into the range), on the CPU (tests) by the torch form from this rank's share."""
     ranges = [dctx.node_range(s, n_nodes) for s in range(dctx.pieces)]
+    nf, nb = needed_rows(edge_index, n_nodes, dctx) if dctx.exchange == "needed" else (None, None)
     if edge_type.device.type == "cuda":
         from .plan import build_graph_plans_device
         return RankPlans(build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
-                                                  ranges=[(r, r) for r in ranges], split=split, dw_tiles=dw_tiles, paths=paths))
+                                                  ranges=[(r, r) for r in ranges], split=split, dw_tiles=dw_tiles, paths=paths), nf, nb)
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = edge_type.to(torch.int64)
     w = edge_weights(src, dst, rel, num_relations, aggr)
@@ -129,7 +190,7 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
         fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk, split)
         bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk, split)
         out.append(GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(fm.sum())))
-    return RankPlans(out)
+    return RankPlans(out, nf, nb)
 
 
 def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext,
@@ -143,15 +204,18 @@ def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr,
     return cached_graph_plans(
         edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split, dw_tiles=dw_tiles,
         paths=paths if isinstance(paths, str) else tuple(paths), widths=widths, builder=build,
-        extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, tuple(dctx.bounds)))
+        extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, tuple(dctx.bounds), dctx.exchange))
 
 
 def attach(module: torch.nn.Module, n_nodes: int, n_edges: int, group=None, edge_index: Optional[Tensor] = None,
-           pieces: int = PIECES, balance: Optional[bool] = None) -> None:
+           pieces: int = PIECES, balance: Optional[bool] = None, exchange: str = "full", emulate=None) -> None:
     """Switch every RGCNConv under ``module`` to the edge-partitioned path for the current process group
     (``n_nodes`` / ``n_edges`` of the graph the module will see: they fix the tile size and with it the
-    tile-aligned node ranges; ``edge_index``: lets the cut follow the edge counts, see make_context)."""
+    tile-aligned node ranges; ``edge_index``: lets the cut follow the edge counts, see make_context).
+    ``exchange="needed"`` (opt-in): a rank receives only the rows its plans read -- owned and read rows bit-identical to the
+    full exchange, unread rows NOT written (conv.DistContext); for layers whose output feeds another partitioned layer over
+    the same graph.  ``emulate=(world, rank)``: one process stands in for one rank, no collectives (bench.py)."""
     for m in module.modules():
         if isinstance(m, RGCNConv):
             tile = m.layout(n_nodes, n_edges)[0]
-            m.dist = make_context(n_nodes, tile, group, pieces, edge_index, balance)
+            m.dist = make_context(n_nodes, tile, group, pieces, edge_index, balance, exchange, emulate)

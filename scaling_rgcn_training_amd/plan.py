@@ -484,7 +484,7 @@ def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: i
 
     def launch_rounds(n_tiles):
         # tile times one launch takes: a workgroup (one per CU, 256 CUs) walks up to 16 tiles, start-up ~4 % of a tile;
-        # the library picks the count the same way (csrc/rgcn_kernels.hip tiles_per_workgroup)
+        # the library picks the count the same way (csrc/rgcn_kernels_shared.h tiles_per_workgroup)
         return min(math.ceil(math.ceil(n_tiles / k) / 256) * (k + 0.04) for k in range(1, 17))
 
     cands = [(t, c) for c in CHUNKS for t in range(64, 513, 16)
@@ -497,7 +497,7 @@ def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: i
 
 
 def run_metadata(slot_dstl: Tensor, tile: int):
-    """Per slot, for the forward kernel's run-sum (csrc/rgcn_kernels.hip stage B/C), precomputed here so
+    """Per slot, for the forward kernel's run-sum (csrc/rgcn_tile_fp32_kernel.h / rgcn_tile3p.hip: the Y-orientation run-sum product), precomputed here so
     the kernel spends no vector instructions on it: inside every 16-slot MFMA row tile, slots with equal
     destination are adjacent (tiles are sorted by destination) and form a RUN; the run's sum is written by
     its LAST slot only.  Returns (slot_acc, tile_dup).  slot_acc = (position 0..15 inside the row tile of the

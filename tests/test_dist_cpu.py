@@ -65,6 +65,44 @@ def _worker(rank, world, port, ret, n, e, tile, pieces, skew=False, balance=None
             b, e_ = p.fwd.node_begin, p.fwd.node_end
             dw += torch.from_numpy(emulate_dw(p.fwd, x.numpy(), dg.numpy()[b:e_], r + 1, din, dout))
     dist.all_reduce(dw)
+    # ---- exchange = "needed" (opt-in): a rank receives only the rows its plans read.  Owned and read rows bit-identical to the
+    # full exchange; every other row is never written (poisoned with NaN here) and never read: a SECOND layer walked over the
+    # exchanged matrix (forward over the forward output, transposed over the dX output) must come out NaN-free and equal
+    ctx2 = rdist.make_context(n, tile, pieces=pieces, edge_index=ei, balance=balance, exchange="needed")
+    ctx2.poison_unread = True
+    assert ctx2.bounds == ctx.bounds
+    plans2 = rdist.rank_plans(ei, et, n, r, tile, "mean", ctx2)
+    nf, nb = plans2.needed_fwd, plans2.needed_bwd
+    assert nf is not None and nb is not None
+
+    def gather2(plan_list, feat, w_mats, b_vec, width, needed):
+        def launch(pl, rows):
+            rows[:pl.n_owned] = torch.from_numpy(emulate_spmm(pl, feat, w_mats, b_vec))
+        return _gather_pieces(ctx2, plan_list, launch, width, n, torch.device("cpu"), dtype=torch.float64, needed=needed)
+
+    w_t = np.transpose(w_all, (0, 2, 1))
+    for plist, feat, wm, bv, width, need, full_res in (([p.fwd for p in plans2.pieces], x.numpy(), w_all, bias.numpy(), dout, nf, out),
+                                                       ([p.bwd for p in plans2.pieces], dg.numpy(), w_t, None, din, nb, dx)):
+        got = gather2(plist, feat, wm, bv, width, need)
+        read = torch.zeros(n, dtype=torch.bool)
+        for s_ in range(ctx2.pieces):
+            b_, e_ = ctx2.node_range(s_, n)
+            read[b_:e_] = True
+            read[need.recv_idx[s_]] = True
+            assert len(need.recv_splits[s_]) == world and need.recv_splits[s_][rank] == 0 and need.send_splits[s_][rank] == 0
+        assert torch.equal(got[read], full_res[read]), "owned + read rows bit-identical to the full exchange"
+        assert torch.isnan(got[~read]).all(), "rows no plan of this rank reads are not written"
+        assert int(read.sum()) - sum(ctx2.node_range(s_, n)[1] - ctx2.node_range(s_, n)[0] for s_ in range(ctx2.pieces)) == need.rows_needed
+        # the next layer in that direction, over this rank's own plans: it must not touch an unwritten row
+        w_next = w_t if need is nf else w_all
+        for pl in plist:
+            if pl.n_owned:
+                a = emulate_spmm(pl, got.numpy(), w_next, None)
+                assert np.isfinite(a).all() and np.array_equal(a, emulate_spmm(pl, full_res.numpy(), w_next, None))
+    # what the peers' lists say about the cut: every remote row a rank reads is sent by exactly its owner
+    tot = torch.tensor([sum(sum(sp) for sp in nf.send_splits), sum(sum(sp) for sp in nf.recv_splits)], dtype=torch.int64)
+    dist.all_reduce(tot)
+    assert int(tot[0]) == int(tot[1]), "rows sent == rows received over all ranks"
     if rank == 0:
         ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(),
                                        dg.numpy())

@@ -38,9 +38,12 @@ def _worker(rank, world, port, ret, dw_direct):
     from scaling_rgcn_training_amd import conv as C
     flags = {"0": _lib.FLAG_DW_RING, "2": _lib.FLAG_DW_DIRECT}.get(dw_direct, 0)
     # "skew-ep": the hub graph with the path choice left to the layer -- every piece's forward on the edge-parallel kernels
-    if dw_direct in ("tiles", "skew", "skew-ep"):
+    # "needed": the opt-in exchange in which a rank receives only the rows its plans read (all_to_all_single with split sizes);
+    # unread rows are poisoned with NaN here and the read ones must be bit-identical to the single-rank layer
+    if dw_direct in ("tiles", "skew", "skew-ep", "needed", "needed-skew"):
         C.DW_TILES_MIN_EDGES = 1
-    skew = dw_direct.startswith("skew")
+    skew = "skew" in dw_direct
+    needed = dw_direct.startswith("needed")
     n, e, r, din, dout = 3000, 40000, 6, 64, 64
     ei, et = O.synthetic_graph(n, e, r, seed=2, skew=skew)
     w, root, bias = O.synthetic_params(r, din, dout, seed=2)
@@ -58,9 +61,10 @@ def _worker(rank, world, port, ret, dw_direct):
             conv.root.copy_(root)
             conv.bias.copy_(bias + 0.25)
         if partitioned:
-            rdist.attach(conv, n, e, edge_index=ei)
+            rdist.attach(conv, n, e, edge_index=ei, exchange="needed" if needed else "full")
             assert conv.dist is not None and conv.dist.world == world
             assert conv.dist.uniform == (not skew)
+            conv.dist.poison_unread = needed
         xd = x.to(dev).requires_grad_(True)
         out = conv(xd, ei.to(dev), et.to(dev))
         out.backward(dg.to(dev))
@@ -68,6 +72,21 @@ def _worker(rank, world, port, ret, dw_direct):
         if partitioned and dw_direct in ("tiles", "skew"):
             owned = sum(1 for pc in conv._plans(xd, ei.to(dev), et.to(dev)).pieces if pc.fwd.n_owned > 0)
             assert conv.dist.stats.get("dw_tiles_pieces", 0) == owned > 0, "every piece's d_weight on the tile-major kernel"
+        if partitioned and needed:
+            pl = conv._plans(xd, ei.to(dev), et.to(dev))
+            dctx = conv.dist
+            masks = []
+            for need in (pl.needed_fwd, pl.needed_bwd):
+                read = torch.zeros(n, dtype=torch.bool)
+                for s_ in range(dctx.pieces):
+                    b_, e_ = dctx.node_range(s_, n)
+                    read[b_:e_] = True
+                    read[need.recv_idx[s_].cpu()] = True
+                masks.append(read.numpy())
+            o, gx = out.detach().cpu().numpy(), xd.grad.cpu().numpy()
+            assert np.isnan(o[~masks[0]]).all() and np.isnan(gx[~masks[1]]).all(), "unread rows are not written"
+            assert 0 < pl.needed_fwd.rows_needed <= pl.needed_fwd.rows_remote
+            return (o, gx, conv.weight.grad.cpu().numpy(), conv.root.grad.cpu().numpy(), conv.bias.grad.cpu().numpy(), masks)
         if dw_direct == "skew-ep":
             pl = conv._plans(xd, ei.to(dev), et.to(dev))
             pcs = pl.pieces if partitioned else [pl]
@@ -81,6 +100,10 @@ def _worker(rank, world, port, ret, dw_direct):
         if dw_direct == "skew-ep":      # per-destination sums in slot order: a piece's units pack differently from the whole graph's
             np.testing.assert_allclose(part[0], single[0], rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(single[0]).max())))
             np.testing.assert_allclose(part[1], single[1], rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(single[1]).max())))
+        elif needed:
+            mf, mb = part[5]
+            assert np.array_equal(single[0][mf], part[0][mf]), "owned + read rows of the forward output bit-identical"
+            assert np.array_equal(single[1][mb], part[1][mb]), "owned + read rows of dX bit-identical"
         else:
             assert np.array_equal(single[0], part[0]), "partitioned forward must be bit-identical (tile-aligned ranges)"
             assert np.array_equal(single[1], part[1]), "partitioned dX must be bit-identical"
@@ -98,7 +121,7 @@ def _worker(rank, world, port, ret, dw_direct):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dw_direct", ["0", "2", "tiles", "skew", "skew-ep"])
+@pytest.mark.parametrize("dw_direct", ["0", "2", "tiles", "skew", "skew-ep", "needed", "needed-skew"])
 def test_two_ranks_one_gpu_partitioned_layer_equals_single_rank(dw_direct):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
@@ -110,3 +133,60 @@ def test_two_ranks_one_gpu_partitioned_layer_equals_single_rank(dw_direct):
         p.join(300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert ret.get(timeout=5) == "ok"
+
+
+@pytest.mark.parametrize("exchange", ["full", "needed"])
+def test_emulated_world_8_ranks_stitch_to_the_single_rank_layer(exchange):
+    """``dist.attach(..., emulate=(world, rank))`` (bench.py --emulate-world): ONE process builds rank r's plans of the world-8
+    cut and launches rank r's kernels with the collectives skipped.  The eight ranks' owned rows, stitched, are the
+    single-GPU layer bit for bit (forward and dX); the eight partial weight gradients add up to the single-GPU ones."""
+    from oracle import rgcn_oracle as O
+    from scaling_rgcn_training_amd import conv as C, dist as rdist
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    from scaling_rgcn_training_amd.plan import clear_plan_cache
+    dev = torch.device("cuda:0")
+    old = C.DW_TILES_MIN_EDGES
+    C.DW_TILES_MIN_EDGES = 1
+    try:
+        n, e, r, d, world = 20000, 300000, 6, 64, 8
+        ei, et = O.synthetic_graph(n, e, r, seed=9)
+        w, root, bias = O.synthetic_params(r, d, d, seed=9)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(n, d, generator=g).to(dev)
+        dg = torch.randn(n, d, generator=g).to(dev)
+        eid, etd = ei.to(dev), et.to(dev)
+
+        def run(emulate):
+            conv = RGCNConv(d, d, r).to(dev)
+            conv.path = "ring"
+            with torch.no_grad():
+                conv.weight.copy_(w)
+                conv.root.copy_(root)
+                conv.bias.copy_(bias + 0.5)
+            if emulate is not None:
+                rdist.attach(conv, n, e, edge_index=eid, pieces=2, exchange=exchange, emulate=emulate)
+                assert conv.dist.emulate and conv.dist.world == world and conv.dist.rank == emulate[1]
+            xd = x.clone().requires_grad_(True)
+            out = conv(xd, eid, etd)
+            out.backward(dg)
+            torch.cuda.synchronize()
+            return conv, out.detach(), xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad
+
+        _, o1, gx1, gw1, gr1, gb1 = run(None)
+        o8, gx8 = torch.full_like(o1, float("nan")), torch.full_like(gx1, float("nan"))
+        gw8, gr8, gb8 = torch.zeros_like(gw1), torch.zeros_like(gr1), torch.zeros_like(gb1)
+        for rk in range(world):
+            conv, o, gx, gw, gr, gb = run((world, rk))
+            for s in range(conv.dist.pieces):
+                b, e_ = conv.dist.node_range(s, n)
+                o8[b:e_], gx8[b:e_] = o[b:e_], gx[b:e_]
+            gw8 += gw
+            gr8 += gr
+            gb8 += gb
+        assert torch.equal(o8, o1) and torch.equal(gx8, gx1), "the ranks' owned rows are the single-GPU rows"
+        for a, b_, what in ((gw8, gw1, "d_weight"), (gr8, gr1, "d_root"), (gb8, gb1, "d_bias")):
+            tol = 2e-5 * max(1.0, float(b_.abs().max()))
+            assert float((a - b_).abs().max()) <= tol, what
+    finally:
+        C.DW_TILES_MIN_EDGES = old
+        clear_plan_cache()

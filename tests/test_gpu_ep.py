@@ -206,3 +206,45 @@ def test_device_edge_plan_is_bit_identical_to_the_torch_twin(dev, n, e, r, skew,
         tp = got.as_tile_plan()
         assert tp.layout == 2 and tp.n_chunks == got.n_units and torch.equal(tp.rel_order, torch.arange(got.n_units, device=dev, dtype=torch.int32))
     del keep
+
+
+def test_heavy_part_of_a_few_units_on_a_graph_of_several_pseudo_tiles(dev):
+    """more than 32,768 owned nodes (the heavy pseudo plan's tile bound) and ONE hub whose heavy (dst, relation)
+    segments fill fewer 64-slot units than the pseudo plan has tiles -- n_chunks < n_tiles, which check_plan refused for every
+    layout.  Forward on the edge-parallel path, backward with weight.requires_grad, through the module; against the float64
+    oracle."""
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    from scaling_rgcn_training_amd.plan import clear_plan_cache
+    n, r, din, dout = 200_000, 4, 16, 8
+    ei, et = O.synthetic_graph(n, 300_000, r, seed=21)
+    g = torch.Generator().manual_seed(4)
+    hub_src = torch.randint(0, n, (3 * 300,), generator=g)
+    hub = torch.stack([hub_src, torch.full((900,), 777)])
+    ei = torch.cat([ei, hub], 1)
+    et = torch.cat([et, torch.arange(3).repeat_interleave(300)])
+    w, root, bias = O.synthetic_params(r, din, dout, seed=6)
+    x = torch.randn(n, din, generator=g)
+    dg = torch.randn(n, dout, generator=g)
+    conv = RGCNConv(din, dout, r).to(dev)
+    conv.path = ("ep", "ring")
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.root.copy_(root)
+        conv.bias.copy_(bias)
+    xd = x.to(dev).requires_grad_(True)
+    eid, etd = ei.to(dev), et.to(dev)
+    out = conv(xd, eid, etd)
+    plans = conv._plans(xd, eid, etd)
+    hv = plans.ep_fwd.heavy
+    assert hv is not None and hv.n_seg == 3, "the hub's three segments are aggregated before the transform"
+    tp = plans.ep_fwd.heavy_tile_plan()
+    assert tp.n_chunks < tp.n_tiles, "the case check_plan used to refuse"
+    out.backward(dg.to(dev))
+    torch.cuda.synchronize()
+    ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
+    c_out, c = abs_condition(x, ei, et, w, root, bias, dg)
+    assert_close(out.detach().cpu().numpy(), ref, c_out, "hub out")
+    assert_close(xd.grad.cpu().numpy(), gr["x"], c["x"], "hub d_x")
+    assert_close(conv.weight.grad.cpu().numpy(), gr["weight"], c["weight"], "hub d_weight")
+    assert_close(conv.root.grad.cpu().numpy(), gr["root"], c["root"], "hub d_root")
+    clear_plan_cache()

@@ -83,6 +83,13 @@ def test_only_the_producer_split_kernel_walks_a_layout_3_plan(dev):
     with pytest.raises(_lib.RgcnLibraryError) as err:          # nor do the relation-major weight-gradient kernels
         _lib.bwd_dw(_lib.plan_struct(plans.fwd), x, 64, x, 64, dw, dr, db, 0)
     assert err.value.status == _lib.ERR_PLAN
+    with pytest.raises(_lib.RgcnLibraryError) as err:          # nor the tile-major one (its walk table and its launch: layout 0 only)
+        _lib.dw_tiles_walk(_lib.plan_struct(plans.fwd), dev)
+    assert err.value.status == _lib.ERR_PLAN
+    walk = torch.zeros(r, _lib.dw_tiles_geometry()[1] + 1, dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.RgcnLibraryError) as err:
+        _lib.bwd_dw_tiles(_lib.plan_struct(plans.fwd), walk, x, 64, x, 64, dw, 0)
+    assert err.value.status == _lib.ERR_PLAN
 
 
 def test_the_module_picks_layout_3_and_agrees_with_layout_0(dev):
