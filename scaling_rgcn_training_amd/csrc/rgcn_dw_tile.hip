@@ -72,20 +72,23 @@ constexpr int kDwTileMaxRel = 32;
 // nearest) and starts the next period from zero, with the SIGN of the period's products flipped (the weight of every slot times
 // -1 on odd periods; the fold subtracts those).  Why: v_mfma_f32_16x16x32_bf16 aligns every product to the accumulator's exponent
 // and TRUNCATES it there -- an error of one sign, proportional to ulp(accumulator), that a long-lived accumulator turns into a
-// bias growing with the rows per slab (-7.5e-2 on d_weight at 12M edges per relation, profiles/r03b_*).  A period of 64 units
-// (~3.5K rows) keeps ulp(accumulator) ~60x smaller than a whole launch's; alternating signs make consecutive periods' biases
-// cancel instead of add.  The slab is private to the wave: no atomics, the same sum order every run.  16 KiB read + written per
-// fold = 0.5 MiB per wave and launch at the headline config (17 folds), ~1 GB per launch against 29.8.
+// bias growing with the rows per slab (-7.5e-2 on d_weight at 12M edges per relation against the exact-fp32 form's +2e-4,
+// profiles/r03b_*).  A period keeps ulp(accumulator) small; alternating signs make consecutive periods' biases cancel instead
+// of add.  The slab is private to the wave: no atomics, the same sum order every run.  Measured at 12M edges per relation
+// (profiles/r04a_dw_fold_error.txt: worst error / mean signed error against float64; exact-fp32 form 5.0e-2 / +2.2e-4) and at the
+// headline config (launch, A/B on one box, profiles/r04a_dw_fold_timing.txt: no fold 6.65-6.70 ms):
+//     period 16 units 3.3e-3 / -1.6e-5, 7.05 ms | 64: 4.8e-3 / -1.8e-4, 6.81 | 128: 6.71 | 256: 1.1e-2 / -2.9e-4, 6.72
+//     64 without the sign flip: 2.2e-2 / -1.7e-2 (the flip is worth two orders of magnitude of bias)
+// 128 units (~7K rows): within 1 % of the launch without folds, worst error 0.15 x and bias ~1 x the exact-fp32 form's.
+// The cost is the fold's read-modify-write draining the wave's prefetch queue (16 x {load 16 B, add, store 16 B} per lane);
+// the same fold as 64 no-return global_atomic_add_f32 per lane (RGCN_DW_FOLD_ATOMIC=1, equally deterministic on a private slab)
+// was SLOWER: 6.95 ms at 64 units, 7.31 at 32, 8.33 at 16.
 #ifndef RGCN_DW_FLUSH_UNITS
-#define RGCN_DW_FLUSH_UNITS 64
+#define RGCN_DW_FLUSH_UNITS 128
 #endif
 #ifndef RGCN_DW_FLUSH_SIGNS
 #define RGCN_DW_FLUSH_SIGNS 1
 #endif
-// 1: the fold as 64 no-return global_atomic_add_f32 per lane instead of 16 x (load 16 B, add, store 16 B): nothing to wait for
-// (the read-modify-write form drains the wave's prefetch queue in front of every fold: +1.6 % per launch at 64 units, A/B below).
-// Still deterministic: the slab is private to the wave, atomics of one wave to one address retire in issue order, and the
-// add at the L2 atomic unit rounds to nearest like v_add_f32.
 #ifndef RGCN_DW_FOLD_ATOMIC
 #define RGCN_DW_FOLD_ATOMIC 0
 #endif
@@ -388,10 +391,14 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     // MFMAs, not at the top of the iteration; sched_barrier only binds the scheduler inside a block).  A compiler-level memory
     // clobber after each batch keeps the loads where issue_half puts them: a read cannot be moved across it.
     auto pin_loads = [] { asm volatile("" ::: "memory"); };
-    // slab += sgn * acc, acc = 0 (split form; the slab was cleared by the host-side memset)
+    // slab += sgn * acc, acc = 0 (the slab was cleared by the host-side memset).  Both forms fold: the exact-fp32 form rounds every
+    // product to nearest, so it has no bias to cancel (sgn stays +1), but a chain of ~7K rows instead of a launch's worth keeps its
+    // rounding errors those of a blocked sum.  Its MFMAs are inline asm the compiler's hazard recognizer does not see: explicit wait
+    // states before the accumulators are read (as in front of the final store)
     float* const slab = a.slabs + ((size_t)p * a.num_rel + (have ? rel : 0)) * (64 * 64);
     auto fold_into_slab = [&](float sgn) {
         if (!have) return;
+        if constexpr (!SPLIT) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #if RGCN_DW_FOLD_ATOMIC
 #pragma unroll
         for (int ia = 0; ia < 4; ++ia)
@@ -477,10 +484,10 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             else compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             ++k;
-            if constexpr (SPLIT && kDwFlushUnits > 0) {
+            if constexpr (kDwFlushUnits > 0) {
                 if (k % (kDwFlushUnits > 0 ? kDwFlushUnits : 1) == 0) {      // wave-uniform: k counts this wave's units
                     fold_into_slab(sgn);
-                    if (RGCN_DW_FLUSH_SIGNS) sgn = -sgn;
+                    if (SPLIT && RGCN_DW_FLUSH_SIGNS) sgn = -sgn;
                 }
             }
             ix_cur = ix_nxt;
@@ -510,7 +517,7 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the accumulators are read by plain stores the compiler schedules: keep them clear of the last asm MFMA
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    if constexpr (SPLIT && kDwFlushUnits > 0) {
+    if constexpr (kDwFlushUnits > 0) {
         fold_into_slab(sgn);
         return;
     }
