@@ -402,7 +402,7 @@ def main():
         for k in ("all_gather", "all_gather_bytes", "all_reduce", "all_reduce_bytes"):
             dctx.stats[k] = 0
         dctx.stats["wait_events"] = []
-        dctx.stats["dw_tiles_pieces"] = 0
+        dctx.stats["dw_tiles_pieces"] = dctx.stats["dw_tiles_rank"] = 0
         dctx.time_waits = True
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
@@ -444,6 +444,8 @@ def main():
                     "max": float(rank_rows.max()), "mean": float(rank_rows.mean()), "max_over_mean": float(rank_rows.max() / rank_rows.mean()),
                     "per_block_max_over_mean": float(bc.max() / bc.mean())},
                 "d_weight_pieces_on_tile_major_kernel_per_step": st.get("dw_tiles_pieces", 0) / args.steps,
+                # full exchange: one tile-major launch per rank over a contiguous node range of its own (dist.dw_range)
+                "d_weight_rank_launches_on_tile_major_kernel_per_step": st.get("dw_tiles_rank", 0) / args.steps,
                 # which piece's gather the launch stream had to wait for (mean ms per gather; the last piece has no kernels
                 # left to hide under: its share is the exposed tail the pipeline depth trades against launch count)
                 "exposed_ms_per_piece": [v / n_gathers for v in per_piece],
@@ -501,6 +503,12 @@ def main():
         if psd is not None:
             _lib.bwd_dw_tiles(psd, plans.dw_walk, xd, d, dg, d, dw, kf)
             _lib.bwd_dw_root(xd, d, dg, d, dr, db)       # (the module enqueues it on a side stream beside dX: conv.py)
+            return
+        if world > 1 and getattr(plans, "dw_rank", None) is not None and plans.dw_rank[0] is not None:
+            dwp_, walk_ = plans.dw_rank       # full exchange: one launch over the rank's own contiguous range (conv.py backward)
+            b_, e_ = dwp_.node_begin, dwp_.node_end
+            _lib.bwd_dw_tiles(_lib.plan_struct(dwp_), walk_, xd, d, dg[b_:e_], d, dw, kf)
+            _lib.bwd_dw_root(xd[b_:e_], d, dg[b_:e_], d, dr, db)
             return
         if world > 1:
             for fp_, dwp_, walk_ in piece_dw:

@@ -359,6 +359,24 @@ class _RGCNLayerFn(torch.autograd.Function):
             pieces = [plans] if dctx is None else plans.pieces
             pinned = flags & (_lib.FLAG_DW_RING | _lib.FLAG_DW_DIRECT | _lib.FLAG_POINTER_GATHER)
             acc = None
+            rank_dw = getattr(plans, "dw_rank", None) if dctx is not None else None
+            if rank_dw is not None and not pinned and _lib.buffer_addressable(n, xp.shape[1]):
+                # full exchange: x and g are replicated, so this rank's share of the weight gradients is ONE contiguous node
+                # range of its own (dist.dw_range) -- one tile-major launch + the streaming root part, whatever the forward's pieces
+                dwp_, walk_ = rank_dw
+                if dwp_ is None:        # an empty range
+                    acc = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+                    pieces = []
+                b, e = (dwp_.node_begin, dwp_.node_end) if dwp_ is not None else (0, 0)
+                if dwp_ is not None and _lib.buffer_addressable(e - b, gp.shape[1]):
+                    acc = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+                    pw, pr, pb = views(acc)
+                    if need_w:
+                        _lib.bwd_dw_tiles(_lib.plan_struct(dwp_), walk_, xp, din, gp[b:e], dout, pw, flags)
+                    if need_root or need_bias:
+                        _lib.bwd_dw_root(xp[b:e], din, gp[b:e], dout, pr, pb)
+                    dctx.stats["dw_tiles_rank"] = dctx.stats.get("dw_tiles_rank", 0) + 1
+                    pieces = []
             for pc in pieces:
                 fp = pc.fwd_walk
                 if fp.n_owned <= 0:

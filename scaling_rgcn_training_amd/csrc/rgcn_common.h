@@ -138,6 +138,35 @@ __device__ __forceinline__ int4 ldc4(const int* p, long idx4) {
     return make_int4(v[0], v[1], v[2], v[3]);
 }
 
+// The same loads through a SCALAR BUFFER descriptor: s_buffer_load_dword takes its byte offset from one SGPR, so a loop that
+// walks several per-chunk arrays in step pays ONE s_add per iteration for all of them (ldc's 64-bit index arithmetic is 4-5
+// scalar instructions per load, ~25 of a consumer wave's ~70 per chunk in rgcn_tile3p_kernel), and an offset past num_records
+// reads 0 -- no clamp, no branch for "one past the end".  Inline asm: the compiler does not know the result arrives later, so
+// NOTHING may touch the destination (not even a copy) before sbuf_wait names it.
+__device__ __forceinline__ i32x4 make_srsrc(const void* base, long bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xFFFFull));
+    r[2] = __builtin_amdgcn_readfirstlane((int)(bytes < 0 ? 0 : (bytes > 0x7FFFFFFCl ? 0x7FFFFFFCl : bytes)));
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void sbuf_load(int& dst, i32x4 rsrc, unsigned byte_off) {
+    // (readfirstlane: where the optimiser has rewritten the running offset in terms of a loop counter it keeps in a vector
+    // register, the operand would otherwise reach the asm as a VGPR -- "illegal VGPR to SGPR copy"; folded away where it is scalar)
+    const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)byte_off);
+    asm volatile("s_buffer_load_dword %0, %1, %2" : "=s"(dst) : "s"(rsrc), "s"(off) : "memory");
+}
+// everything this wave has in flight on lgkmcnt (scalar loads return out of order: there is no counted wait for them) has
+// landed; the loaded values are operands so that no use of them can be scheduled above the wait
+__device__ __forceinline__ void sbuf_wait(int& a, int& b, int& c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c)::"memory");
+}
+__device__ __forceinline__ void sbuf_wait(int& a) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)::"memory");
+}
+
 __host__ __device__ inline int padded_width(int w) {
     if (w < 1 || w > 128) return 0;
     return w <= 16 ? 16 : (w <= 32 ? 32 : (w <= 64 ? 64 : 128));

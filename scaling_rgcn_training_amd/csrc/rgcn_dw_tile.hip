@@ -426,6 +426,11 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             }
     };
     float sgn = 1.f;
+    // the fold period of THIS wave: kDwFlushUnits where the wave has a long walk (the headline: ~1,000 units per wave), an eighth
+    // of its walk (at least 16 units) where it is shorter -- there the folds cost nothing that matters and a chain of ~1K rows
+    // instead of ~7K keeps the sums as accurate as ATen's blocked ones (tests/test_gpu_parity.py holds 2 x the CPU loop's error)
+    const int fold_period = kDwFlushUnits > 0 ? min(kDwFlushUnits, max(16, nun >> 3)) : 0;
+    int fold_left = fold_period;
     dma_tile(t0, 0);
     int k = 0;
     int uid_cur = unit_of(0), uid_nxt = unit_of(1), uid_nn = unit_of(2);
@@ -485,7 +490,8 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             __builtin_amdgcn_sched_barrier(0);
             ++k;
             if constexpr (kDwFlushUnits > 0) {
-                if (k % (kDwFlushUnits > 0 ? kDwFlushUnits : 1) == 0) {      // wave-uniform: k counts this wave's units
+                if (--fold_left == 0) {      // wave-uniform
+                    fold_left = fold_period;
                     fold_into_slab(sgn);
                     if (SPLIT && RGCN_DW_FLUSH_SIGNS) sgn = -sgn;
                 }

@@ -26,6 +26,7 @@ struct TileArgs {
     int act;            // forward only: RGCN_ACT_* applied in the tile store
     int dbg;            // diagnostic builds only (RGCN_DBG)
     int n_tiles;        // tiles of the plan
+    int n_chunks;       // chunks of the plan (bounds of the scalar buffer loads of the per-chunk arrays)
     int merged;         // the plan is layout 3 (runs of equal (destination, relation) compacted: rgcn_plan.hip compact_runs_kernel)
     int tiles_per_wg;   // consecutive tiles one workgroup walks (rgcn_tile_kernel): the next tile's first gathers are in
                         // flight while the finished tile is stored

@@ -57,6 +57,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
     a.ldm = ldm;
     a.act = act;
     a.n_tiles = plan->n_tiles;
+    a.n_chunks = plan->n_chunks;
     a.merged = plan->layout == 3 ? 1 : 0;
     a.tiles_per_wg = tiles_per_workgroup(plan->n_tiles);
 #ifdef RGCN_TPW_ENV        // experiment build only (tools/debug/tpw_sweep.py)

@@ -153,10 +153,29 @@ def needed_rows(edge_index: Tensor, n_nodes: int, dctx: DistContext):
 class RankPlans:
     """The graph plans of one rank: one forward / transposed pair per owned block (piece)."""
 
-    def __init__(self, pieces, needed_fwd: Optional[NeededRows] = None, needed_bwd: Optional[NeededRows] = None):
+    def __init__(self, pieces, needed_fwd: Optional[NeededRows] = None, needed_bwd: Optional[NeededRows] = None, dw_rank=None):
         self.pieces = pieces
         self.num_edges = sum(p.num_edges for p in pieces)
         self.needed_fwd, self.needed_bwd = needed_fwd, needed_bwd      # exchange = "needed" (conv._gather_pieces)
+        # full exchange: (tile-major d_weight plan, walk table) over ONE contiguous node range of this rank (dw_range) -- x and
+        # the upstream gradient are replicated, so the weight gradients' cut is free: one launch per rank, not one per piece
+        self.dw_rank = dw_rank
+
+
+def dw_range(edge_index: Tensor, n_nodes: int, world: int, rank: int, tile: int = 320):
+    """the contiguous node range whose in-edges rank ``rank`` sums into d_weight / d_root / d_bias: ``world`` ranges of about equal
+    rows walked (in-edges + one root row per node), cut at multiples of ``tile``; float64 prefix sums of the replicated edge
+    list, so every rank computes the same cut"""
+    n_tiles = (n_nodes + tile - 1) // tile
+    c = torch.bincount(edge_index[1] // tile, minlength=n_tiles).double().cpu() + float(tile)
+    cum = torch.cumsum(c, 0)
+    total = float(cum[-1]) if n_tiles else 0.0
+    cut = [0]
+    for i in range(1, world):
+        t = int(torch.searchsorted(cum, torch.tensor(total * i / world, dtype=torch.float64))) + 1
+        cut.append(max(cut[-1], min(t, n_tiles)))
+    cut.append(n_tiles)
+    return min(cut[rank] * tile, n_nodes), min(cut[rank + 1] * tile, n_nodes)
 
 
 def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int, tile: int,
@@ -169,8 +188,15 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
     nf, nb = needed_rows(edge_index, n_nodes, dctx) if dctx.exchange == "needed" else (None, None)
     if edge_type.device.type == "cuda":
         from .plan import build_graph_plans_device
-        return RankPlans(build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
-                                                  ranges=[(r, r) for r in ranges], split=split, dw_tiles=dw_tiles, paths=paths), nf, nb)
+        from . import _lib
+        # exchange = "needed": x holds the rows this rank's FORWARD blocks read, so d_weight stays on the pieces' own plans
+        rank_dw = dw_tiles and dctx.exchange == "full" and paths[0] != "ep"
+        extras = {}
+        pcs = build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
+                                       ranges=[(r, r) for r in ranges], split=split, dw_tiles=dw_tiles and not rank_dw, paths=paths,
+                                       rank_dw_range=dw_range(edge_index, n_nodes, dctx.world, dctx.rank, _lib.dw_tiles_geometry()[0]) if rank_dw else None,
+                                       extras=extras)
+        return RankPlans(pcs, nf, nb, extras.get("dw_rank"))
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = edge_type.to(torch.int64)
     w = edge_weights(src, dst, rel, num_relations, aggr)

@@ -589,17 +589,21 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
                              aggr: str = "mean", fwd_range: Optional[Tuple[int, int]] = None,
                              bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
                              ranges=None, split: bool = False, dw_tiles: bool = False,
-                             paths: Tuple[str, str] = ("ring", "ring")):
+                             paths: Tuple[str, str] = ("ring", "ring"), rank_dw_range: Optional[Tuple[int, int]] = None,
+                             extras: Optional[dict] = None):
     """The plans built by the HIP library itself (csrc/rgcn_plan.hip through rgcn_edge_weights / rgcn_plan_build_*):
     what every GPU forward uses.  ``ranges``: a list of (begin, end) owned ranges -> a list of GraphPlans that share one
-    edge-weight pass and one workspace (dist.py: one pair of plans per owned block)."""
+    edge-weight pass and one workspace (dist.py: one pair of plans per owned block).  ``rank_dw_range`` (dist.py, full exchange):
+    ONE tile-major weight-gradient plan over that contiguous node range besides the pieces' forward / transposed plans, returned
+    in ``extras["dw_rank"] = (plan, walk table)`` -- both operands of d_weight are replicated, so its cut need not be the
+    forward's and one launch per rank replaces one per piece."""
     from . import _lib
     if chunk not in CHUNKS:
         raise ValueError(f"chunk must be one of {CHUNKS}")
     graph, keep = _lib.graph_struct(edge_index, edge_type, n_nodes, num_relations)
     e = int(edge_type.shape[0])
     rs = ranges if ranges is not None else [(fwd_range or (0, n_nodes), bwd_range or (0, n_nodes))]
-    own_max = max([1] + [max(f[1] - f[0], b[1] - b[0]) for f, b in rs])
+    own_max = max([1] + [max(f[1] - f[0], b[1] - b[0]) for f, b in rs] + ([rank_dw_range[1] - rank_dw_range[0]] if rank_dw_range else []))
     ws_tile = min(tile, _lib.dw_tiles_geometry()[0]) if dw_tiles else tile      # the smallest tile sizes the group arrays
     ws = _lib.plan_workspace(e, own_max, num_relations, ws_tile, edge_type.device)
     try:
@@ -639,6 +643,14 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
                 gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, fb, fe, ws, False, aligned=False)
                 gp.dw_walk = _lib.dw_tiles_walk(_lib.plan_struct(gp.dw), edge_type.device)
         out.append(gp)
+    if rank_dw_range is not None and extras is not None and paths[0] != "ep":
+        t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
+        if num_relations <= max_rel:
+            if rank_dw_range[1] > rank_dw_range[0]:
+                pl = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, rank_dw_range[0], rank_dw_range[1], ws, False, aligned=False)
+                extras["dw_rank"] = (pl, _lib.dw_tiles_walk(_lib.plan_struct(pl), edge_type.device))
+            else:
+                extras["dw_rank"] = (None, None)      # an empty range (fewer tiles than ranks): this rank adds zeros
     del keep
     return out if ranges is not None else out[0]
 
@@ -695,8 +707,11 @@ _CACHE_MAX_BYTES = int(float(_os.environ.get("RGCN_PLAN_CACHE_GB", "48")) * (1 <
 
 def _plans_nbytes(plans) -> int:
     pieces = getattr(plans, "pieces", None) or [plans]
-    return sum(sum(q.nbytes() for q in (p.fwd, p.bwd, getattr(p, "dw", None), getattr(p, "ep_fwd", None), getattr(p, "ep_bwd", None))
-                   if q is not None) for p in pieces)
+    extra = sum(q.nbytes() for q in (getattr(plans, "needed_fwd", None), getattr(plans, "needed_bwd", None)) if q is not None)
+    if getattr(plans, "dw_rank", None) is not None and plans.dw_rank[0] is not None:
+        extra += plans.dw_rank[0].nbytes()
+    return extra + sum(sum(q.nbytes() for q in (p.fwd, p.bwd, getattr(p, "dw", None), getattr(p, "ep_fwd", None), getattr(p, "ep_bwd", None))
+                           if q is not None) for p in pieces)
 
 
 def cached_graph_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relations: int,

@@ -70,8 +70,11 @@ def _worker(rank, world, port, ret, dw_direct):
         out.backward(dg.to(dev))
         torch.cuda.synchronize()
         if partitioned and dw_direct in ("tiles", "skew"):
+            # full exchange: x and g are replicated, so a rank's d_weight is ONE tile-major launch over a contiguous range of its own
+            assert conv.dist.stats.get("dw_tiles_rank", 0) == 1 and conv.dist.stats.get("dw_tiles_pieces", 0) == 0
+        if partitioned and needed:
             owned = sum(1 for pc in conv._plans(xd, ei.to(dev), et.to(dev)).pieces if pc.fwd.n_owned > 0)
-            assert conv.dist.stats.get("dw_tiles_pieces", 0) == owned > 0, "every piece's d_weight on the tile-major kernel"
+            assert conv.dist.stats.get("dw_tiles_pieces", 0) == owned > 0, "needed rows: every piece's d_weight on the tile-major kernel with its own plan"
         if partitioned and needed:
             pl = conv._plans(xd, ei.to(dev), et.to(dev))
             dctx = conv.dist

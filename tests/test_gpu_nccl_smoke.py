@@ -72,7 +72,7 @@ def _worker(port, ret):
         torch.cuda.synchronize()
         if partitioned:
             assert conv.dist.stats["all_gather"] == 8 and conv.dist.stats["all_reduce"] == 1
-            assert conv.dist.stats.get("dw_tiles_pieces", 0) == 4, "every piece's d_weight ran the tile-major kernel"
+            assert conv.dist.stats.get("dw_tiles_rank", 0) == 1, "the rank's d_weight ran the tile-major kernel, one launch over its own contiguous range"
         return [t.cpu().numpy() for t in (out.detach(), xd.grad, conv.weight.grad, conv.root.grad, conv.bias.grad)]
 
     single = run(False)

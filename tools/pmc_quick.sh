@@ -11,6 +11,6 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
     i=$((i + 1))
     timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/q_sq$i -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ladder > $O/q_sq$i.log 2>&1
 done
-python3 tools/debug/pmc_summary.py $O/q_sq1 $O/q_sq2 $O/q_sq3 $O/q_sq4 > $O/${TAG}_pmc_sq.txt
+python3 tools/pmc_summary.py $O/q_sq1 $O/q_sq2 $O/q_sq3 $O/q_sq4 > $O/${TAG}_pmc_sq.txt
 rm -rf $O/q_sq1 $O/q_sq2 $O/q_sq3 $O/q_sq4
 grep -A18 "rgcn_tile" $O/${TAG}_pmc_sq.txt
