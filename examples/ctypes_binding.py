@@ -52,7 +52,7 @@ def load(path):
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    assert lib.rgcn_abi_version() == 15
+    assert lib.rgcn_abi_version() == 16
     return lib
 
 

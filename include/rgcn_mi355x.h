@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 15
+#define RGCN_ABI_VERSION 16
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -90,7 +90,7 @@ typedef struct rgcn_plan {
                             * 2: no tiles -- dense relation-major units for rgcn_bwd_dw only (rgcn_edge_units);
                             * 3 (chunk = 128): layout 0 with the rows of a (destination, relation) run on ONE slot where a chunk is
                             * a whole (tile, relation) group with runs of at most 3 rows: heads on slots 0 .. H-1, second rows on
-                            * row tile 7 - h / 16 (place h % 16), third rows on row tile 5; chunk_cnt counts the head row tiles,
+                            * row tile 7 - h / 16 (place h % 16), third rows on the row tile below those (6 or 5); chunk_cnt counts the head row tiles,
                             * chunk_flags bits 20-23 repeat every chunk's row-tile count, bits 16-17 / 18 count the row tiles of
                             * second / third rows, bit 19 "the rows of a run differ in
                             * weight" (a shadow slot's slot_acc then holds the float weight / head's weight).  Walked by rgcn_fwd / rgcn_bwd_dx with RGCN_FLAG_SPLIT_PRODUCERS on 64 x 64 layers only (the

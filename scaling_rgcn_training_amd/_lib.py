@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",

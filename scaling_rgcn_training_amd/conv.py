@@ -48,6 +48,11 @@ _TEAM_LAYOUT_DEFAULT = os.environ.get("RGCN_TEAM_LAYOUT", "0") == "1"
 _MERGE_RUNS_DEFAULT = os.environ.get("RGCN_MERGE_RUNS", "1") == "1"
 _PATH_DEFAULT = os.environ.get("RGCN_PATH", "auto")       # auto | ring | ep
 SPLIT_PRODUCERS_TILE = 224       # the largest tile whose fp32 accumulator fits beside the kernel's two 48 KiB ring slots
+# exact-fp32 forward / dX of 64 x 64 layers on layout-3 plans (round 4): the largest tile it takes.  Measured at the headline
+# config, forward / dX launch, A/B on one box (profiles/r04g_exact_merge_timing.txt): layout 0 at the cost model's 352: 10.42 /
+# 10.33 ms; layout 3 at 352 (40 % of the chunks compacted, 5.8 % fewer head row tiles) 10.12 / 10.18; at 320: 10.21 / 10.19; at
+# 288 (60 %, -10 %): 10.32 / 10.41 -- smaller tiles compact more chunks but pay more of them: the cap stays at 352
+EXACT_MERGE_TILE = int(os.environ.get("RGCN_EXACT_MERGE_TILE", 352))
 DW_TILES_MIN_EDGES = 4_000_000
 
 _ACT_CODES = {None: _lib.ACT_NONE, "relu": _lib.ACT_RELU, "sigmoid": _lib.ACT_SIGMOID}
@@ -561,7 +566,8 @@ class RGCNConv(nn.Module):
                     and _lib.buffer_addressable(n, _round4(self.out_channels)))
         # layout 3 only where nothing but rgcn_tile3p_kernel walks the forward / transposed plans: the split kernels unpinned
         # (no kernel flags), d_weight on its own tile-major plan, d_root / d_bias on the plan-free streaming kernel
-        if (not split and self.merge_runs and dw_tiles and self.kernel_flags == 0 and self._use_split_producers(chunk)):
+        if (not split and self.merge_runs and dw_tiles and self.kernel_flags == 0 and
+                (self._use_split_producers(chunk) or self._exact_merge(chunk))):
             split = 3
         if self.dist is None:
             paths = self.path if self.path == "auto" else ((self.path, self.path) if isinstance(self.path, str) else tuple(self.path))
@@ -579,16 +585,42 @@ class RGCNConv(nn.Module):
                                  paths=paths, widths=(self.in_channels, self.out_channels))
 
     def _use_split_producers(self, chunk: int) -> bool:
+        """whether a plan of ``self.layout`` with that chunk runs on the bf16 x 3 kernel (layout() returns 128-slot chunks for a
+        64 x 64 layer with split_producers only where that kernel is the modelled choice, at a tile it has room for)"""
         from .plan import padded_width
         return (self.split_producers and chunk == 128 and not _ENV_TILE
                 and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64)
 
+    def _exact_merge(self, chunk: int) -> bool:
+        """the exact-fp32 kernel on layout-3 plans: 64 x 64 layers, 128-slot chunks, where the bf16 x 3 kernel is switched off"""
+        from .plan import padded_width
+        return (not self.split_producers and self.merge_runs and chunk == 128 and not _ENV_TILE
+                and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64)
+
     def layout(self, n_nodes: int, n_edges: int) -> Tuple[int, int]:
         """(tile, chunk) of this layer's plans on a graph of that size: ``layout_for``, capped at the producer-split kernel's
-        tile where that kernel will run (dist.attach aligns the ranks' node ranges to the same tile)."""
+        tile where that kernel will run (dist.attach aligns the ranks' node ranges to the same tile), or at the tile that leaves
+        the exact-fp32 kernel's chunks room for their shadow row tiles where it will walk layout-3 plans."""
         tile, chunk = layout_for(self.in_channels, self.out_channels, n_nodes, n_edges, self.num_relations)
+        if self._use_split_producers(128) and not _ENV_CHUNK:
+            # 64 x 64 with the bf16 x 3 kernel available: its own layout (128-slot chunks, tiles up to 224, its own cycles per chunk
+            # and row tile) against the exact-fp32 kernel's, by modelled launch time -- round 4: on a 100k-node / 1M-edge graph the
+            # exact model's (400, 64) kept the layer off the faster kernel: 0.416 ms per step replayed against 0.333 at (208, 128)
+            from .plan import choose_layout
+            args = (n_nodes, n_edges, self.num_relations, self.in_channels, self.out_channels)
+            t0, c0, cost0 = choose_layout(*args, with_cost=True)
+            t3, c3, cost3 = choose_layout(*args, kernel="bf16x3", with_cost=True)
+            if cost3 <= cost0:
+                return t3, c3
+            if c0 == 128:      # (the exact-fp32 kernel with 128-slot chunks would be taken for the other one: keep it on 64)
+                tile, chunk = layout_for(self.in_channels, self.out_channels, n_nodes, n_edges, self.num_relations)
+                return min(tile, SPLIT_PRODUCERS_TILE), chunk
+            return t0, c0
         if self._use_split_producers(chunk):
             tile = min(tile, SPLIT_PRODUCERS_TILE)
+        elif (self._exact_merge(chunk) and self.dw_tiles and self.kernel_flags == 0 and self.num_relations <= 32
+              and n_edges >= DW_TILES_MIN_EDGES):
+            tile = min(tile, EXACT_MERGE_TILE)
         return tile, chunk
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None, *,

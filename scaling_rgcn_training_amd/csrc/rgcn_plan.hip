@@ -496,7 +496,9 @@ __global__ void row_tile_kernel(const u32* dstl, u32 n_row_tiles, u32 chunk, u32
 // and only where it is simple: chunks that are a whole (tile, relation) group, runs of at most 3 rows, at most 32 runs of 2+ rows
 // and 16 of 3; anything else keeps its layout-0 slots (always correct: the kernel reads the shadow counts per chunk).  New chunk:
 // heads (first row of every run; runs of 3 first, then of 2, then single rows, each class in destination order) on slots 0 .. H-1;
-// the second row of head h on row tile 7 - h / 16, place h % 16; the third on row tile 5, place h -- the SAME lane of the same
+// the second row of head h on row tile 7 - h / 16, place h % 16; the third on the row tile right below the second rows' (7 - ns1:
+// row tile 6 with one tile of second rows, 5 with two; round 3 had it fixed at 5, which shut out every chunk of six head row
+// tiles with a run of three -- most chunks at tiles above 224), place h -- the SAME lane of the same
 // producer wave holds a head and its shadows, one row tile register apart.  chunk_cnt = 16 ceil(H / 16); chunk_flags bits 20-23 =
 // the chunk's row tiles (every chunk of the plan, compacted or not), bits 16-17 =
 // row tiles with second rows, bit 18 = a row tile with third rows, bit 19 = some run's rows differ in weight (the transposed
@@ -549,7 +551,7 @@ __global__ void __launch_bounds__(kCompactThreads) compact_runs_kernel(u32 n_chu
     }
     if (n2 + n3 == 0 || n3 > 16u || n2 + n3 > 32u) return;
     const u32 H = n1 + n2 + n3, nh = (H + 15u) / 16u, ns1 = (n2 + n3 + 15u) / 16u, ns2 = n3 > 0 ? 1u : 0u;
-    if (nh >= nt || nh > (ns2 ? 5u : 8u - ns1)) return;
+    if (nh >= nt || nh + ns1 + ns2 > 8u) return;
     // clear the chunk, then write heads and shadows
     for (u32 i = 0; i < 128u; ++i) {
         slot_src[base + i] = (int32_t)n_nodes;
@@ -576,7 +578,7 @@ __global__ void __launch_bounds__(kCompactThreads) compact_runs_kernel(u32 n_chu
             slot_acc[s1] = (int32_t)__float_as_uint(__fdiv_rn(__uint_as_float(lw[j + 1]), __uint_as_float(lw[j])));
         }
         if (len == 3) {
-            const size_t s2 = base + 5u * 16u + h;
+            const size_t s2 = base + (size_t)(7u - ns1) * 16u + h;
             slot_src[s2] = lsrc[j + 2];
             slot_w[s2] = __uint_as_float(lw[j + 2]);
             slot_row[s2] = row;

@@ -187,9 +187,9 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     auto issue_meta = [&](P3Rows& r, int k) { p3_load_int(r.meta, meta_src + (size_t)(c0 + k) * kP3CH); };
     auto store_meta = [&](const P3Rows& r, int k) { meta_dst[(k & 1) * 2 * kP3CH] = r.meta; };
     // fl: the chunk's flags -- bits 16-17 / 18 of a layout-3 chunk (rgcn_plan.hip compact_runs_kernel): row tiles 7, 6 hold the
-    // second rows of the (destination, relation) runs whose first rows sit in row tiles 0, 1, row tile 5 the third rows of row
-    // tile 0's: same lane, added in fp32 before the cut (aggregate, then transform); bit 19: a shadow row times its weight ratio
-    // first.  One uniform branch where a chunk has no shadows; the sums replace the head rows in place (the set is reloaded anyway).
+    // second rows of the (destination, relation) runs whose first rows sit in row tiles 0, 1, the row tile below them (6 with one
+    // tile of second rows, 5 with two) the third rows of row tile 0's: same lane, added in fp32 before the cut (aggregate, then
+    // transform); bit 19: a shadow row times its weight ratio first.  One uniform branch where a chunk has no shadows; the sums replace the head rows in place (the set is reloaded anyway).
     auto split_store = [&](P3Rows& r, int k, int nrt, int fl) {
         char* slot = ring + (k & 1) * kP3SlotBytes;
         if (fl & (7 << 16)) {
@@ -198,11 +198,11 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
             if (pre) {      // the rows of a run differ in weight -- a shadow row times (its weight / its head's)
                 auto wt = [&](int t) { return __int_as_float(__builtin_amdgcn_ds_bpermute((32 + 4 * t + rq) * 4, r.meta)); };
                 r.v[0] += r.v[7] * wt(7);
-                if (ns2) r.v[0] += r.v[5] * wt(5);
+                if (ns2) r.v[0] += ns1 >= 2 ? r.v[5] * wt(5) : r.v[6] * wt(6);
                 if (ns1 >= 2) r.v[1] += r.v[6] * wt(6);
             } else {
                 r.v[0] += r.v[7];
-                if (ns2) r.v[0] += r.v[5];
+                if (ns2) r.v[0] += ns1 >= 2 ? r.v[5] : r.v[6];
                 if (ns1 >= 2) r.v[1] += r.v[6];
             }
         }

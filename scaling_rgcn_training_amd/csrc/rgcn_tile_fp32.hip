@@ -78,9 +78,9 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
         const int st3 = launch_tile3p(b, plan->n_tiles, plan->layout, stream);
         if (st3 != RGCN_ERR_LDS || plan->layout == 3) return st3;
     }
-    // layout 3 (runs of equal (destination, relation) on ONE slot, their other rows in shadow row tiles): only the kernel above
-    // adds the shadows
-    if (plan->layout == 3) return RGCN_ERR_PLAN;
+    // layout 3 (runs of equal (destination, relation) on ONE slot, their other rows in shadow row tiles): besides the kernel above
+    // the exact-fp32 kernel of 64 x 64 layers adds the shadows (its producers: rgcn_tile_fp32_kernel.h), through buffer descriptors only
+    if (plan->layout == 3 && !(KP == 64 && NP == 64 && plan->chunk == 128 && a.x_bytes != 0)) return RGCN_ERR_PLAN;
     return dispatch_tile(KP, NP, a, plan->n_tiles, plan->chunk, (hipStream_t)stream);
 }
 

@@ -66,30 +66,109 @@ __device__ __forceinline__ void tile_producer_loop(const TileArgs& a, float* rin
                 const int kk = k < nch ? k : nch - 1;
                 return a.slot_src[(size_t)(c0 + kk) * CH + 64 * half + lane];
             };
-            auto issue_part = [&](int k, int idxv) {
+            // ---- layout-3 plans (rgcn_plan.hip compact_runs_kernel; 64-wide rows, 128-slot chunks): aggregate, then transform.
+            // The rows of a (destination, relation) run sit on ONE head slot (row tiles 0 / 1 of the chunk) and their second / third
+            // rows on the SHADOW row tiles 7, 6 / 5 at the head's place.  The head rows travel by LDS-DMA like every row; the wave
+            // (third rows: the row tile right below the second rows', 6 or 5.)  The wave that owns row tiles 0 and 1 (wave 0) loads the shadow rows into REGISTERS with the same lane geometry (lane = row
+            // 4 i + rsub of its tile, 16-byte position p: exactly where the DMA puts the head's piece), waits for both, and adds
+            // them to the head rows in LDS before the barrier hands the slot to the consumers -- who never see a shadow tile
+            // (chunk_cnt counts the head row tiles).  The other waves' shadow slots become padding (no gather traffic).
+            // chunk_flags: bits 16-17 row tiles of second rows, 18 a tile of third rows, 19 a shadow row times (its weight / its
+            // head's) first -- the float in the shadow slot's slot_acc --, 20-23 the head row tiles.
+            constexpr bool kCanMerge = KP == 64 && CH == 128 && BUF;
+            const bool merged = kCanMerge && a.merged != 0;
+            const bool shadow_wave = merged && row0 == 0;
+            auto load_word = [&](int k) { return merged ? ldc(a.chunk_flags, c0 + (k < nch ? k : nch - 1)) : 0; };
+            auto load_shadow = [&](const int* arr, int k) {      // lanes 16 .. 63 <-> slots 80 .. 127 (row tiles 5, 6, 7)
+                const int kk = k < nch ? k : nch - 1;
+                return shadow_wave ? arr[(size_t)(c0 + kk) * CH + 64 + lane] : 0;
+            };
+            f32x4 sh[12];      // shadow rows in flight: [0..3] row tile 7, [4..7] row tile 6 (second rows), [8..11] the third rows' tile
+            auto issue_part = [&](int k, int idxv, int wd, int sidx) {
                 const int chunk = c0 + k, buf = k % NBUF;
+                if (merged) {      // slots of the shadow row tiles (and beyond the heads): padding for the DMA
+                    const int heads = ((wd >> 20) & 15) * 16;
+                    idxv = 64 * half + lane < heads ? idxv : a.n_rows;
+                }
                 gather.template issue_part<NOPS_PART>(a.x, a.x_bytes, a.n_rows, a.ldx, idxv,
                                                       ring + (buf * CH + row0) * KP, op0);
                 if (meta) {
                     dma4(a.slot_w + (size_t)chunk * CH + 64 * half + lane, wring + buf * CH + 64 * half);
                     dma4(a.slot_acc + (size_t)chunk * CH + 64 * half + lane, dring + buf * CH + 64 * half);
                 }
+                if constexpr (kCanMerge) {
+                    if (shadow_wave && (wd & (7 << 16))) {
+                        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.x, a.x_bytes);
+                        const int ns1 = (wd >> 16) & 3;
+                        auto rows4 = [&](f32x4* dst, int lane0) {      // four DMA-shaped loads: rows lane0 + 4 i + rsub of the half
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int ix = __builtin_amdgcn_ds_bpermute((lane0 + 4 * i) * 4 + gather.perm_addr, sidx);
+                                dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rsrc, (int)(__umul24((unsigned)ix, gather.rowb[i % 4]) + gather.coff[i % 4]), 0, 0));
+                            }
+                        };
+                        rows4(sh, 48);
+                        if (ns1 >= 2) rows4(sh + 4, 32);
+                        if ((wd >> 18) & 1) rows4(sh + 8, ns1 >= 2 ? 16 : 32);      // third rows: row tile 5 behind two tiles of second rows, else 6
+                    }
+                }
+            };
+            // after the wave's DMAs and shadow loads have landed: head row += shadow row (x ratio), in LDS, this wave's own rows
+            auto merge_part = [&](int k, int wd, int srat) {
+                if constexpr (kCanMerge) {
+                    if (!(shadow_wave && (wd & (7 << 16)))) return;
+                    f32x4* slot = (f32x4*)(ring + ((k % NBUF) * CH) * KP);
+                    const int ns1 = (wd >> 16) & 3;
+                    const bool third = ((wd >> 18) & 1) != 0, pre = ((wd >> 19) & 1) != 0;
+                    auto ratio = [&](int lane0, int i) {
+                        return pre ? __int_as_float(__builtin_amdgcn_ds_bpermute((lane0 + 4 * i) * 4 + gather.perm_addr, srat)) : 1.f;
+                    };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {      // heads of row tile 0: rows 4 i + rsub = f32x4 index (4 i) * 16 + lane
+                        f32x4 h = slot[i * 64 + lane];
+                        h += sh[i] * ratio(48, i);
+                        if (third) h += sh[8 + i] * ratio(ns1 >= 2 ? 16 : 32, i);
+                        slot[i * 64 + lane] = h;
+                    }
+                    if (ns1 >= 2) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {  // heads of row tile 1
+                            f32x4 h = slot[(4 + i) * 64 + lane];
+                            h += sh[4 + i] * ratio(32, i);
+                            slot[(4 + i) * 64 + lane] = h;
+                        }
+                    }
+                }
             };
             int idx_cur = load_idx(0);
-            issue_part(0, idx_cur);                       // (its index vector is waited for here, once per tile)
+            int wd_cur = load_word(0), sidx_cur = load_shadow(a.slot_src, 0), srat_cur = load_shadow(a.slot_acc, 0);
+            issue_part(0, idx_cur, wd_cur, sidx_cur);     // (its index vector is waited for here, once per tile)
             idx_cur = load_idx(1);
+            int wd_nxt = load_word(1), srat_nxt = load_shadow(a.slot_acc, 1);
+            sidx_cur = load_shadow(a.slot_src, 1);
             wait_vmcnt<0>();                              // chunk 0 landed (and the indices of chunk 1)
+            merge_part(0, wd_cur, srat_cur);
+            wd_cur = wd_nxt;
+            srat_cur = srat_nxt;
             wg_barrier();                                 // chunk 0 (and the accumulator init) visible
             for (int it = 0; it < nch; ++it) {
                 STAMP(p0);
-                int idx_next = idx_cur;
+                int idx_next = idx_cur, sidx_next = sidx_cur;
                 if (it + 1 < nch) {
-                    issue_part(it + 1, idx_cur);
+                    issue_part(it + 1, idx_cur, wd_cur, sidx_cur);
                     idx_next = load_idx(it + 2);          // youngest operation: lands with the rows
+                    sidx_next = load_shadow(a.slot_src, it + 2);
+                    srat_nxt = load_shadow(a.slot_acc, it + 2);
+                    wd_nxt = load_word(it + 2);
                 }
                 STAMP(p1);
                 wait_vmcnt<0>();                          // chunk it + 1 landed
+                if (it + 1 < nch) merge_part(it + 1, wd_cur, srat_cur);
                 idx_cur = idx_next;
+                sidx_cur = sidx_next;
+                wd_cur = wd_nxt;
+                srat_cur = srat_nxt;
                 STAMP(p2);
                 wg_barrier();
                 STAMP(p3);
@@ -633,7 +712,8 @@ static int launch_tile(const TileArgs& a, int n_tiles, int chunk, hipStream_t st
     if (chunk == 128) {
         // 128-slot chunks: built for the widths whose ring slots leave room for a useful tile (KP <= 64)
         if constexpr (KP <= 64) {
-            if (bytes(3) <= cap) return launch_tile_nbuf<KP, NP, 3, 128>(a, n_tiles, bytes(3), stream);
+            // (layout-3 plans: the two-slot ring, whose producers all issue every chunk and wave 0 adds the shadow rows)
+            if (bytes(3) <= cap && !a.merged) return launch_tile_nbuf<KP, NP, 3, 128>(a, n_tiles, bytes(3), stream);
             if (bytes(2) <= cap) return launch_tile_nbuf<KP, NP, 2, 128>(a, n_tiles, bytes(2), stream);
         }
         return RGCN_ERR_LDS;

@@ -235,7 +235,7 @@ def compact_runs(plan: TilePlan) -> TilePlan:
     Chunk-local, and only where it is simple: chunks that are a whole (tile, relation) group, runs of at most 3 rows, at most 32
     runs of 2+ rows and 16 of 3; any other chunk keeps its layout-0 slots.  New chunk: heads (first row of every run; runs of 3
     first, then of 2, then single rows, each class in destination order) on slots 0 .. H-1; the second row of head h on row tile
-    7 - h // 16, place h % 16; the third on row tile 5, place h.  ``chunk_cnt`` = 16 ceil(H / 16); ``chunk_flags`` bits 20-23 = the chunk's
+    7 - h // 16, place h % 16; the third on row tile 7 - ns1 (right below the tiles of second rows), place h.  ``chunk_cnt`` = 16 ceil(H / 16); ``chunk_flags`` bits 20-23 = the chunk's
     row tiles (every chunk, compacted or not), bits 16-17 = row tiles with second rows, bit 18 = a row tile with third rows, bit 19 = some run's rows differ in weight (the producers then
     scale a shadow row by its weight / its head's weight -- the float32 in the shadow's ``slot_acc`` -- before they add it).  Every
     slot keeps its own weight and its run's row (a walk over all slots with a weight still sums the layer: tests/plan_emulator.py).
@@ -300,7 +300,7 @@ def compact_runs(plan: TilePlan) -> TilePlan:
             continue
         heads = n1 + n2 + n3
         nh, ns1, ns2 = (heads + 15) // 16, (n2 + n3 + 15) // 16, 1 if n3 else 0
-        if nh >= nt or nh > (5 if ns2 else 8 - ns1):
+        if nh >= nt or nh + ns1 + ns2 > 8:
             continue
         src[base:base + 128] = n_nodes
         wbits[base:base + 128] = 0
@@ -322,7 +322,7 @@ def compact_runs(plan: TilePlan) -> TilePlan:
                 src[s1], wbits[s1], row[s1] = rows[j0 + 1][0], rows[j0 + 1][2], tbase + d0
                 acc[s1] = ratio(rows[j0 + 1][2], w0)
             if ln == 3:
-                s2 = base + 5 * 16 + h
+                s2 = base + (7 - ns1) * 16 + h
                 src[s2], wbits[s2], row[s2] = rows[j0 + 2][0], rows[j0 + 2][2], tbase + d0
                 acc[s2] = ratio(rows[j0 + 2][2], w0)
         cnt[c] = nh * 16
@@ -449,8 +449,18 @@ def padded_width(w: int) -> int:
     return 16 if w <= 16 else 32 if w <= 32 else 64 if w <= 64 else 128
 
 
-def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int):
-    """(tile, chunk) for a layer: output nodes per tile and edge slots per chunk.
+# measured ms per launch at the headline config over the model's cycle count, per kernel: what makes the two kernels' costs comparable
+# (exact fp32: 10.15 ms where the model says 8.6; bf16 x 3: 8.4 ms where its model -- 1,800 cycles per chunk, 420 per row tile,
+# DESIGN.md 8.0f -- says 9.2)
+_KERNEL_MODEL = {"fp32": (800.0, 650.0, 1.18), "bf16x3": (1800.0, 420.0, 0.91)}
+P3_MAX_TILE = 224          # rgcn_tile3p_kernel: two 48 KiB ring slots + the fp32 accumulator in 160 KiB
+
+
+def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int, kernel: str = "fp32",
+                  with_cost: bool = False):
+    """(tile, chunk) for a layer: output nodes per tile and edge slots per chunk.  ``kernel="bf16x3"``: the layout for
+    rgcn_tile3p_kernel (64 x 64 layers: 128-slot chunks, tiles up to 224, its own per-chunk / per-row-tile cycles);
+    ``with_cost``: also the modelled time of one launch, comparable between the two kernels (conv.RGCNConv.layout picks with it).
 
     Cost model of the forward / dX kernel, calibrated on the 10M-node / 100M-edge graph (tools/debug/stamps.py): a
     chunk costs ~800 cycles whatever it holds (barrier, metadata, pipeline fill and drain) and every 16-row MFMA tile
@@ -475,25 +485,33 @@ def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: i
         sd = math.sqrt(g)
         return sum(0.5 * math.erfc((unit * k - g) / (sd * math.sqrt(2.0))) for k in range(0, int(g / unit) + 6))
 
+    c_chunk, c_tile, scale = _KERNEL_MODEL[kernel]
+    p3 = kernel == "bf16x3"
+
     def cost(t, chunk):
         g = density * t
-        ring_penalty = 1.0 if lds(t, chunk, 3) <= LDS_BYTES else 1.03
-        per_rel = expect_ceil(g, chunk) * 800.0 + (g / 16.0 + 0.5) * 650.0 if g > 0 else 0.0
-        root = math.ceil(t / chunk) * 800.0 + (t / 16.0) * 650.0
-        return ring_penalty * (max(1, num_relations) * per_rel + root) / t      # cycles per output node
+        ring_penalty = 1.0 if (p3 or lds(t, chunk, 3) <= LDS_BYTES) else 1.03
+        per_rel = expect_ceil(g, chunk) * c_chunk + (g / 16.0 + 0.5) * c_tile if g > 0 else 0.0
+        root = math.ceil(t / chunk) * c_chunk + (t / 16.0) * c_tile
+        return scale * ring_penalty * (max(1, num_relations) * per_rel + root) / t      # cycles per output node
 
     def launch_rounds(n_tiles):
         # tile times one launch takes: a workgroup (one per CU, 256 CUs) walks up to 16 tiles, start-up ~4 % of a tile;
         # the library picks the count the same way (csrc/rgcn_kernels_shared.h tiles_per_workgroup)
         return min(math.ceil(math.ceil(n_tiles / k) / 256) * (k + 0.04) for k in range(1, 17))
 
-    cands = [(t, c) for c in CHUNKS for t in range(64, 513, 16)
-             if lds(t, c, 2) <= LDS_BYTES and (c == CHUNK or max(kp, np_) <= 64)]
+    if p3:
+        cands = [(t, 128) for t in range(64, P3_MAX_TILE + 1, 16)] if max(kp, np_) == 64 and min(kp, np_) == 64 else []
+    else:
+        cands = [(t, c) for c in CHUNKS for t in range(64, 513, 16)
+                 if lds(t, c, 2) <= LDS_BYTES and (c == CHUNK or max(kp, np_) <= 64)]
     if not cands:
-        return 64, CHUNK
+        return (64, CHUNK, float("inf")) if with_cost else (64, CHUNK)
     # time of a launch ~ rounds x (cycles per tile): on large graphs this is the cost per node, on small ones the round
     # count decides (100k nodes: 285 tiles of 352 are two rounds with the second one a ninth full)
-    return min(cands, key=lambda tc: (round(launch_rounds(math.ceil(n_nodes / tc[0])) * cost(*tc) * tc[0] / 1e3, 1), -tc[0]))
+    key = lambda tc: (round(launch_rounds(math.ceil(n_nodes / tc[0])) * cost(*tc) * tc[0] / 1e3, 1), -tc[0])
+    best = min(cands, key=key)
+    return (best[0], best[1], key(best)[0]) if with_cost else best
 
 
 def run_metadata(slot_dstl: Tensor, tile: int):

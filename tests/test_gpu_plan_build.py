@@ -50,7 +50,8 @@ def test_plan_build_matches_torch_on_golden_topologies(golden, tile, chunk):
 @pytest.mark.parametrize("n,e,r,tile,chunk,skew", [(1500, 20000, 9, 64, 64, False), (3000, 60000, 5, 128, 128, False),
                                                    (20000, 60000, 32, 224, 128, False), (3000, 30000, 32, 224, 128, False),
                                                    (4000, 60000, 5, 352, 128, True), (37, 0, 3, 16, 64, False),
-                                                   (100000, 1200000, 45, 96, 64, True), (50, 5000, 2, 16, 128, False)])
+                                                   (100000, 1200000, 45, 96, 64, True), (50, 5000, 2, 16, 128, False),
+                                                   (9000, 90000, 32, 288, 128, False), (7000, 70000, 32, 352, 128, False)])
 def test_plan_build_matches_torch_on_random_graphs(n, e, r, tile, chunk, skew):
     if e:
         ei, et = O.synthetic_graph(n, e, r, seed=n + e, skew=skew)

@@ -299,11 +299,13 @@ def test_team_placement_walks_and_keeps_parts_disjoint(golden, tile):
     np.testing.assert_allclose(dw[:-1], golden["d_wfull"], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("n,e,r,tile", [(20000, 60000, 32, 224), (3000, 30000, 32, 224), (5000, 100000, 32, 224), (300, 2500, 8, 64)])
+@pytest.mark.parametrize("n,e,r,tile", [(20000, 60000, 32, 224), (3000, 30000, 32, 224), (5000, 100000, 32, 224), (300, 2500, 8, 64),
+                                        (9000, 90000, 32, 288), (7000, 70000, 32, 352)])
 def test_compact_runs_keeps_the_layer_and_its_own_invariants(n, e, r, tile):
     """plan.compact_runs (layout 3; twin of compact_runs_kernel): the walk over all slots still sums the layer (forward and
     transposed plan, whose runs differ in weight); a compacted chunk holds pairwise distinct destinations on its head slots, every
-    shadow sits in its head's lane position (row tile 7 - h // 16 or 5, place h % 16) with its head's output row, the flags'
+    shadow sits in its head's lane position (second rows: row tile 7 - h // 16; third rows: the row tile below those, 7 - ns1;
+    place h % 16) with its head's output row, the flags'
     row-tile count equals chunk_cnt / 16 on EVERY chunk, and no edge row is lost."""
     import numpy as np
     from oracle import rgcn_oracle as O
@@ -336,12 +338,15 @@ def test_compact_runs_keeps_the_layer_and_its_own_invariants(n, e, r, tile):
             heads = row[c, :nh * 16][src[c, :nh * 16] < n]
             assert len(set(heads.tolist())) == len(heads), "a compacted chunk's heads scatter into pairwise distinct rows"
             assert (fl[c] & 0xFFFF) == 0, "so none of its row tiles needs the run-sum"
-            for t, head_tile, shadow in ((7, 0, ns1 >= 1), (6, 1, ns1 >= 2), (5, 0, bool(ns2))):
+            third = 7 - ns1        # third rows: right below the tiles of second rows (round 4; round 3: always row tile 5)
+            layout = [(7, 0, ns1 >= 1)] + ([(6, 1, True), (5, 0, bool(ns2))] if ns1 >= 2 else [(6, 0, bool(ns2)), (5, 0, False)])
+            assert not ns2 or third == (5 if ns1 >= 2 else 6)
+            for t, head_tile, shadow in layout:
                 used = src[c, 16 * t:16 * t + 16] < n
                 if shadow:      # behind the head tiles, every row the output row of the head in the same place
                     assert t >= nh and used.any()
                     assert np.array_equal(row[c, 16 * t:16 * t + 16][used], row[c, 16 * head_tile:16 * head_tile + 16][used])
                 elif t >= nh:
                     assert not used.any()
-            assert nh <= (5 if ns2 else 8 - ns1)
+            assert nh + ns1 + ns2 <= 8
     assert some > 0 or e > 64 * n, "no chunk was compacted: the case tests nothing"
