@@ -368,7 +368,7 @@ def main():
     del weight, root
     if world > 1:
         rdist.attach(conv, n, e, edge_index=ei, pieces=args.pieces or rdist.PIECES,
-                     balance={"auto": None, "on": True, "off": False}[args.balance], exchange=args.exchange)
+                     balance={"auto": None, "on": True, "off": False}[args.balance], exchange=args.exchange, edge_type=et)
     x.requires_grad_(True)
 
     torch.cuda.synchronize()
@@ -432,7 +432,8 @@ def main():
         n_gathers = max(1, len(st["wait_events"]))
         wait_ms = sum(per_piece) / args.steps
         bc = getattr(dctx, "block_costs", None)
-        rank_rows = bc.sum(0) if bc is not None else None        # rows (in- + out-edges + root rows) every rank walks per step
+        # rows (in- + out-edges + root rows) every rank walks per step: its blocks' + its share of the heavy segments' rows
+        rank_rows = bc.sum(0) + float(getattr(dctx, "shared_rows_per_rank", 0.0)) if bc is not None else None
         gather_bytes = n * d * 4 * (world - 1) / world             # what one gather moves INTO a rank
         nf_, nb_ = getattr(plans, "needed_fwd", None), getattr(plans, "needed_bwd", None)
         comm = {"backend": backend, "pieces": dctx.pieces, "cut": "uniform" if dctx.uniform else "balanced by edge count",
@@ -442,7 +443,9 @@ def main():
                                                                   "dx_output": nb_.rows_needed / max(1, nb_.rows_remote)},
                 "rows_walked_per_rank": None if rank_rows is None else {
                     "max": float(rank_rows.max()), "mean": float(rank_rows.mean()), "max_over_mean": float(rank_rows.max() / rank_rows.mean()),
-                    "per_block_max_over_mean": float(bc.max() / bc.mean())},
+                    "per_block_max_over_mean": float(bc.max() / bc.mean()),
+                    # rows of heavy (node, relation) segments dealt over all ranks (edge-parallel directions: eplan.SharedHeavy)
+                    "shared_heavy_rows_per_rank": float(getattr(dctx, "shared_rows_per_rank", 0.0))},
                 "d_weight_pieces_on_tile_major_kernel_per_step": st.get("dw_tiles_pieces", 0) / args.steps,
                 # full exchange: one tile-major launch per rank over a contiguous node range of its own (dist.dw_range)
                 "d_weight_rank_launches_on_tile_major_kernel_per_step": st.get("dw_tiles_rank", 0) / args.steps,

@@ -411,6 +411,8 @@ def ep_aggregate_heavy(ep, x: torch.Tensor, din: int) -> Optional[torch.Tensor]:
     h = getattr(ep, "heavy", None)
     if h is None:
         return None
+    if getattr(h, "shared", None) is not None:
+        raise RgcnLibraryError("this plan's heavy segments are shared across ranks: H comes from ep_aggregate_shared + all-reduce")
     cur = x
     for ptr, idx, w, n_out in h.levels:
         dst = torch.empty(max(n_out, 1), x.stride(0), dtype=torch.float32, device=x.device)
@@ -419,8 +421,21 @@ def ep_aggregate_heavy(ep, x: torch.Tensor, din: int) -> Optional[torch.Tensor]:
     return cur
 
 
+def ep_aggregate_shared(shared, x: torch.Tensor, din: int) -> torch.Tensor:
+    """this rank's share of H[seg] = sum_e w_e x[src_e] over the heavy segments of the whole graph (eplan.SharedHeavy): zeros but
+    for the segments its rows belong to; the all-reduce over the ranks (conv.py) completes it"""
+    hmat = torch.zeros(max(shared.n_seg, 1), x.stride(0), dtype=torch.float32, device=x.device)
+    cur = x
+    for li, (ptr, idx, w, n_out) in enumerate(shared.levels):
+        last = li == len(shared.levels) - 1
+        dst = hmat[shared.seg_lo:shared.seg_lo + n_out] if last else torch.empty(max(n_out, 1), x.stride(0), dtype=torch.float32, device=x.device)
+        ep_segment_sum(cur, ptr, idx, w, n_out, din, dst)
+        cur = dst
+    return hmat
+
+
 def ep_layer(ep, x: torch.Tensor, din: int, packed: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, dout: int,
-             act: int = ACT_NONE, mask: Optional[torch.Tensor] = None, flags: int = 0) -> Optional[torch.Tensor]:
+             act: int = ACT_NONE, mask: Optional[torch.Tensor] = None, flags: int = 0, hmat: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """out[:n_owned] = act(bias + sum over the plan's rows of w * (x[src] @ W_rel)) * (mask > 0): the heavy segments' rows
     summed first (ep_aggregate_heavy), rgcn_ep_transform over the units (and over the heavy part's pseudo rows, gathered from
     H), then one rgcn_ep_segment_sum per level of the plan.  ``out``: [n_owned, ld] with ld a multiple of 4.  Returns H (the
@@ -429,7 +444,8 @@ def ep_layer(ep, x: torch.Tensor, din: int, packed: torch.Tensor, bias: Optional
     ldz = out.stride(0)
     st = _stream(x)
     h = getattr(ep, "heavy", None)
-    hmat = ep_aggregate_heavy(ep, x, din)
+    if hmat is None:      # (given: the all-reduced H of the heavy segments shared across ranks)
+        hmat = ep_aggregate_heavy(ep, x, din)
     with torch.cuda.device(x.device):
         n_light = ep.n_units * 64
         z = torch.empty(max(n_light + (h.n_units * 64 if h is not None else 0), 1), ldz, dtype=torch.float32, device=x.device)

@@ -111,12 +111,15 @@ class DistContext:
     ``stats`` counts what the collectives moved (bench.py reports it per step)."""
 
     def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int, bounds=None, exchange: str = "full",
-                 emulate: bool = False):
+                 emulate: bool = False, split_hubs: bool = True):
         if exchange not in ("full", "needed"):
             raise ValueError("exchange must be 'full' or 'needed'")
         self.group, self.rank, self.world = group, rank, world
         self.pieces = pieces
         self.exchange, self.emulate = exchange, emulate
+        # edge-parallel pieces: the heavy (node, relation) segments of the whole graph are summed by ALL ranks, an equal share of
+        # their rows each, and one small all-reduce completes the sums (eplan.SharedHeavy) -- a hub no longer belongs to one rank
+        self.split_hubs = split_hubs
         self.uniform = bounds is None
         self.piece_rows = piece_rows if self.uniform else None
         self.bounds = [i * piece_rows for i in range(pieces * world + 1)] if self.uniform else [int(b) for b in bounds]
@@ -232,6 +235,20 @@ def _gather_pieces(dctx: "DistContext", plans_list, launch, ld: int, n: int, dev
     return full[:n]
 
 
+def _shared_heavy_sums(shared, x: Tensor, width: int, dctx: "DistContext") -> Optional[Tensor]:
+    """H[segment] = sum of the weighted rows of every heavy (node, relation) segment of the WHOLE graph: this rank's share of the
+    rows (rgcn_ep_segment_sum), then one all-reduce over the ranks (eplan.SharedHeavy)"""
+    if shared is None:
+        return None
+    hmat = _lib.ep_aggregate_shared(shared, x, width)
+    if not dctx.emulate:
+        torch.distributed.all_reduce(hmat, group=dctx.group)
+    dctx.stats["all_reduce"] += 1
+    dctx.stats["all_reduce_bytes"] += hmat.numel() * 4
+    dctx.stats["shared_heavy_rows"] = dctx.stats.get("shared_heavy_rows", 0) + (shared.row_hi - shared.row_lo)
+    return hmat
+
+
 class _RGCNLayerFn(torch.autograd.Function):
     """a = act(sum_r mean-aggregate_r(x) @ W_r + x @ root + bias)   (forward: rgcn_fwd with the activation fused
     into its store; backward: rgcn_bwd_dx on the transposed plan + rgcn_bwd_dw)."""
@@ -265,11 +282,16 @@ class _RGCNLayerFn(torch.autograd.Function):
             # ownership the per-layer all-reduce of SURVEY.md 8e degenerates to an all-gather (each row has
             # exactly one non-zero contributor), issued piece by piece under the next piece's kernels
             # (a piece whose forward runs the edge-parallel path -- a hub's block -- carries an eplan.EdgePlan instead)
+            # (hubs split across ranks, eplan.SharedHeavy: every rank sums its share of the heavy segments' rows, one all-reduce
+            # of the [segments, in] sums, then the owners' pseudo rows go through the transform)
+            hm_f = _shared_heavy_sums(getattr(plans, "shared_fwd", None), xp, din, dctx)
+            ctx.ep_heavy = hm_f
+
             def launch_fwd(pl, rows):
                 if isinstance(pl, TilePlan):
                     _lib.fwd(_lib.plan_struct(pl), xp, din, packed, bs, rows, dout, act, flags)
                 else:
-                    _lib.ep_layer(pl, xp, din, packed, bs, rows, dout, act, None, flags)
+                    _lib.ep_layer(pl, xp, din, packed, bs, rows, dout, act, None, flags, hmat=hm_f)
             out = _gather_pieces(dctx, [p.fwd if p.fwd is not None else p.ep_fwd for p in plans.pieces], launch_fwd, ldo, n, x.device,
                                  needed=plans.needed_fwd if dctx.exchange == "needed" else None)
         ctx.plans, ctx.dctx = plans, dctx
@@ -341,12 +363,14 @@ class _RGCNLayerFn(torch.autograd.Function):
                 dxp = torch.empty(n, ldx, dtype=torch.float32, device=dev)
                 _lib.bwd_dx(_lib.plan_struct(plans.bwd), gp, dout, packed_t, dxp, din, mask, flags)
             else:
+                hm_b = _shared_heavy_sums(getattr(plans, "shared_bwd", None), gp, dout, dctx)
+
                 def launch_dx(pl, rows):
                     m = None if mask is None else mask[pl.node_begin:pl.node_end]
                     if isinstance(pl, TilePlan):
                         _lib.bwd_dx(_lib.plan_struct(pl), gp, dout, packed_t, rows, din, m, flags)
                     else:
-                        _lib.ep_layer(pl, gp, dout, packed_t, None, rows, din, _lib.ACT_NONE, m, flags)
+                        _lib.ep_layer(pl, gp, dout, packed_t, None, rows, din, _lib.ACT_NONE, m, flags, hmat=hm_b)
                 # the exchange of the dX pieces stays in flight under the weight-gradient kernels below (they read x and the
                 # rank's own rows of g, none of the gathered rows); finish_dx() is the wait
                 dxp, finish_dx = _gather_pieces(dctx, [p.bwd if p.bwd is not None else p.ep_bwd for p in plans.pieces], launch_dx, ldx, n, dev,

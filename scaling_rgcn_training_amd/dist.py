@@ -39,7 +39,8 @@ def tile_costs(edge_index: Tensor, n_nodes: int, tile: int) -> Tensor:
     """float64 [n_tiles]: rows a rank that owns the tile walks per layer step -- the edges INTO its nodes (forward plan), the
     edges OUT OF them (transposed plan) and the two root pseudo edges per node."""
     n_tiles = (n_nodes + tile - 1) // tile
-    c = (torch.bincount(edge_index[1] // tile, minlength=n_tiles) + torch.bincount(edge_index[0] // tile, minlength=n_tiles)).double()
+    # (an end point in the tile past the last one -- make_context's sentinel for a row that is no block's cost -- falls off the end)
+    c = (torch.bincount(edge_index[1] // tile, minlength=n_tiles + 1)[:n_tiles] + torch.bincount(edge_index[0] // tile, minlength=n_tiles + 1)[:n_tiles]).double()
     rows = torch.full((n_tiles,), float(tile), dtype=torch.float64, device=c.device)
     rows[-1] = n_nodes - (n_tiles - 1) * tile
     return (c + 2.0 * rows).cpu()
@@ -69,8 +70,16 @@ def balanced_bounds(costs: Tensor, n_nodes: int, tile: int, world: int, pieces: 
     return [0] + [min(int(c) * tile, n_nodes) for c in cut] + [n_nodes]
 
 
+def heavy_edge_masks(edge_index: Tensor, edge_type: Tensor, n_nodes: int):
+    """(edges of heavy (dst, relation) segments, edges of heavy (src, relation) segments) as bool [E] or None: the rows that
+    eplan.SharedHeavy deals over ALL ranks, whatever block their node lies in"""
+    from .eplan import HEAVY, heavy_mask
+    return (heavy_mask(edge_index[1], edge_type, n_nodes, HEAVY), heavy_mask(edge_index[0], edge_type, n_nodes, HEAVY))
+
+
 def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge_index: Optional[Tensor] = None,
-                 balance: Optional[bool] = None, exchange: str = "full", emulate=None) -> Optional[DistContext]:
+                 balance: Optional[bool] = None, exchange: str = "full", emulate=None, edge_type: Optional[Tensor] = None,
+                 split_hubs: bool = True) -> Optional[DistContext]:
     """edge_index given: keep the uniform cut (one in-place all-gather per piece) while its blocks' edge counts stay within
     BALANCE_TOLERANCE of their mean, else cut by edge count (``balance`` True / False pins the choice).
     ``exchange``: "full" | "needed" (conv.DistContext).  ``emulate = (world, rank)``: no process group -- the context of rank
@@ -87,10 +96,26 @@ def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge
     n_tiles = (n_nodes + tile - 1) // tile
     pieces = max(1, min(pieces, n_tiles // world if n_tiles >= world else 1))
     pr = piece_rows(n_nodes, tile, world, pieces)
-    kw = {"exchange": exchange, "emulate": emulate is not None}
+    kw = {"exchange": exchange, "emulate": emulate is not None, "split_hubs": split_hubs}
     ctx = DistContext(group, rank, world, pr, pieces, **kw)
     if edge_index is not None and balance is not False:
-        costs = tile_costs(edge_index, n_nodes, tile)
+        ei_cost, shared_rows = edge_index, 0.0
+        if split_hubs and edge_type is not None and edge_index.shape[1] > 0:
+            # rows of heavy segments are dealt over all ranks (eplan.SharedHeavy) wherever a direction takes the edge-parallel
+            # path: they are not a block's cost.  (The tile kernels would walk them in their block; the cut assumes the path a
+            # hub graph takes.)  What stays in a block: its light rows and one pseudo row per heavy segment (negligible).
+            hf, hb = heavy_edge_masks(edge_index, edge_type, n_nodes)
+            if hf is not None or hb is not None:
+                zero = torch.zeros(edge_index.shape[1], dtype=torch.bool, device=edge_index.device)
+                hf = zero if hf is None else hf
+                hb = zero if hb is None else hb
+                shared_rows = float(hf.sum() + hb.sum()) / world
+                # an edge counts once for its destination's tile (forward) and once for its source's (transposed): drop each side
+                # where it is shared -- a sentinel node past the end keeps the tensor shapes
+                past = n_tiles * tile           # (a node id in the tile after the last one: tile_costs drops it)
+                ei_cost = torch.stack([torch.where(hb, torch.full_like(edge_index[0], past), edge_index[0]),
+                                       torch.where(hf, torch.full_like(edge_index[1], past), edge_index[1])])
+        costs = tile_costs(ei_cost, n_nodes, tile)
         bc = block_costs(costs, ctx.bounds, tile)
         # (the uniform cut pads its last blocks past the graph's end: compare the heaviest block with a block's share of the
         # total, not with a mean the empty trailing blocks pull down)
@@ -98,6 +123,7 @@ def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge
             ctx = DistContext(group, rank, world, 0, pieces, balanced_bounds(costs, n_nodes, tile, world, pieces), **kw)
             bc = block_costs(costs, ctx.bounds, tile)
         ctx.block_costs = bc.view(pieces, world)
+        ctx.shared_rows_per_rank = shared_rows      # rows of heavy segments every rank sums besides its blocks' (eplan.SharedHeavy)
     return ctx
 
 
@@ -153,8 +179,12 @@ def needed_rows(edge_index: Tensor, n_nodes: int, dctx: DistContext):
 class RankPlans:
     """The graph plans of one rank: one forward / transposed pair per owned block (piece)."""
 
-    def __init__(self, pieces, needed_fwd: Optional[NeededRows] = None, needed_bwd: Optional[NeededRows] = None, dw_rank=None):
+    def __init__(self, pieces, needed_fwd: Optional[NeededRows] = None, needed_bwd: Optional[NeededRows] = None, dw_rank=None,
+                 shared_fwd=None, shared_bwd=None):
         self.pieces = pieces
+        # eplan.SharedHeavy per direction: the heavy (node, relation) segments of the whole graph, their rows dealt over the ranks
+        # (hubs split across ranks: conv.py all-reduces the partial H before the pieces' transforms)
+        self.shared_fwd, self.shared_bwd = shared_fwd, shared_bwd
         self.num_edges = sum(p.num_edges for p in pieces)
         self.needed_fwd, self.needed_bwd = needed_fwd, needed_bwd      # exchange = "needed" (conv._gather_pieces)
         # full exchange: (tile-major d_weight plan, walk table) over ONE contiguous node range of this rank (dw_range) -- x and
@@ -195,8 +225,8 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
         pcs = build_graph_plans_device(edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk,
                                        ranges=[(r, r) for r in ranges], split=split, dw_tiles=dw_tiles and not rank_dw, paths=paths,
                                        rank_dw_range=dw_range(edge_index, n_nodes, dctx.world, dctx.rank, _lib.dw_tiles_geometry()[0]) if rank_dw else None,
-                                       extras=extras)
-        return RankPlans(pcs, nf, nb, extras.get("dw_rank"))
+                                       extras=extras, hub_split=(dctx.world, dctx.rank) if dctx.split_hubs else None)
+        return RankPlans(pcs, nf, nb, extras.get("dw_rank"), extras.get("shared_fwd"), extras.get("shared_bwd"))
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = edge_type.to(torch.int64)
     w = edge_weights(src, dst, rel, num_relations, aggr)
@@ -210,13 +240,30 @@ def rank_plans(edge_index: Tensor, edge_type: Tensor, n_nodes: int, num_relation
 
     fg, fs, fr, fw, fpiece = share(dst, src)       # forward: edges INTO my blocks
     bg, bs, br, bw, bpiece = share(src, dst)       # transposed: edges OUT OF my blocks
+    # edge-parallel directions (torch twin of the device path; tests): the pieces' eplan.EdgePlan over the whole edge list, the
+    # heavy segments shared across the ranks where dctx.split_hubs
+    from .eplan import HEAVY, build_edge_plan, build_shared_heavy
+    sh_f = build_shared_heavy(src, dst, rel, w, n_nodes, HEAVY, world, rank) if paths[0] == "ep" and dctx.split_hubs else None
+    sh_b = build_shared_heavy(dst, src, rel, w, n_nodes, HEAVY, world, rank) if paths[1] == "ep" and dctx.split_hubs else None
     out = []
     for s, (b, e) in enumerate(ranges):
         fm, bm = fpiece == s, bpiece == s
-        fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk, split)
-        bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk, split)
-        out.append(GraphPlans(fwd=fwd, bwd=bwd, num_edges=int(fm.sum())))
-    return RankPlans(out, nf, nb)
+        gp = GraphPlans(fwd=None, bwd=None, num_edges=int(fm.sum()))
+        if e <= b:
+            gp.fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk, split)
+            gp.bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk, split)
+            out.append(gp)
+            continue
+        if paths[0] == "ep":
+            gp.ep_fwd = build_edge_plan(src, dst, rel, w, n_nodes, num_relations, b, e, heavy=HEAVY, shared=sh_f)
+        else:
+            gp.fwd = build_plan(fg[fm], fs[fm], fr[fm], fw[fm], n_nodes, num_relations, tile, b, e, chunk, split)
+        if paths[1] == "ep":
+            gp.ep_bwd = build_edge_plan(dst, src, rel, w, n_nodes, num_relations, b, e, heavy=HEAVY, shared=sh_b)
+        else:
+            gp.bwd = build_plan(bg[bm], bs[bm], br[bm], bw[bm], n_nodes, num_relations, tile, b, e, chunk, split)
+        out.append(gp)
+    return RankPlans(out, nf, nb, None, sh_f, sh_b)
 
 
 def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr, dctx: DistContext,
@@ -230,18 +277,21 @@ def cached_rank_plans(edge_index, edge_type, n_nodes, num_relations, tile, aggr,
     return cached_graph_plans(
         edge_index, edge_type, n_nodes, num_relations, tile, aggr, chunk=chunk, split=split, dw_tiles=dw_tiles,
         paths=paths if isinstance(paths, str) else tuple(paths), widths=widths, builder=build,
-        extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, tuple(dctx.bounds), dctx.exchange))
+        extra_key=("rank", dctx.rank, dctx.world, dctx.pieces, tuple(dctx.bounds), dctx.exchange, dctx.split_hubs))
 
 
 def attach(module: torch.nn.Module, n_nodes: int, n_edges: int, group=None, edge_index: Optional[Tensor] = None,
-           pieces: int = PIECES, balance: Optional[bool] = None, exchange: str = "full", emulate=None) -> None:
+           pieces: int = PIECES, balance: Optional[bool] = None, exchange: str = "full", emulate=None,
+           edge_type: Optional[Tensor] = None, split_hubs: bool = True) -> None:
     """Switch every RGCNConv under ``module`` to the edge-partitioned path for the current process group
     (``n_nodes`` / ``n_edges`` of the graph the module will see: they fix the tile size and with it the
     tile-aligned node ranges; ``edge_index``: lets the cut follow the edge counts, see make_context).
     ``exchange="needed"`` (opt-in): a rank receives only the rows its plans read -- owned and read rows bit-identical to the
     full exchange, unread rows NOT written (conv.DistContext); for layers whose output feeds another partitioned layer over
-    the same graph.  ``emulate=(world, rank)``: one process stands in for one rank, no collectives (bench.py)."""
+    the same graph.  ``emulate=(world, rank)``: one process stands in for one rank, no collectives (bench.py).
+    ``edge_type`` + ``split_hubs`` (default on): the cut leaves out the rows of heavy (node, relation) segments, which the
+    edge-parallel path deals over all ranks (eplan.SharedHeavy)."""
     for m in module.modules():
         if isinstance(m, RGCNConv):
             tile = m.layout(n_nodes, n_edges)[0]
-            m.dist = make_context(n_nodes, tile, group, pieces, edge_index, balance, exchange, emulate)
+            m.dist = make_context(n_nodes, tile, group, pieces, edge_index, balance, exchange, emulate, edge_type, split_hubs)

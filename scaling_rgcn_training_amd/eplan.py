@@ -55,7 +55,95 @@ class HeavyPart:
     slot_src: Tensor        # pseudo rows gather row `segment id` of the aggregated matrix H (padding: n_seg)
     slot_w: Tensor          # 1 (the rows' weights went into H)
     slot_row: Tensor
+    shared: object = None   # SharedHeavy: the segments are the WHOLE graph's (dist.py, hubs split across ranks): H comes all-reduced,
+                            # ``levels`` is empty and slot_src holds global segment ids
     _tile_plan: object = field(default=None, repr=False)
+
+
+@dataclass
+class SharedHeavy:
+    """Hubs split ACROSS ranks (round 4, SURVEY.md 8e "ranges balanced by edge count").  Under dist a hub's
+    block belongs to one rank, and a heavy (scatter node, relation) segment -- node 0 of the Zipf graph: 12.7M in-edges, 32
+    segments of ~400K rows -- is that rank's alone: rows walked per rank max / mean 8.3 at world 8.  Here the heavy segments of
+    the WHOLE graph (one direction) form one list, their rows sorted by (segment, gathered row) and dealt over the ranks in equal
+    contiguous shares; a rank sums ITS rows of every segment it touches (rgcn_ep_segment_sum over x, weighted, in levels) into a
+    zero-initialised H[n_seg, width], ONE all-reduce completes H everywhere (the mean normaliser 1 / c is a plan constant, so
+    partial SUMS are all that travels -- the "sum and count" of SURVEY.md 8e with the count folded in at plan time), and the
+    owner of a segment's node puts one pseudo row per segment through the transform, the per-destination sums and the weight
+    gradients exactly as with a rank-local HeavyPart.  At most world - 1 segments are actually cut (their sums differ from the
+    single-rank order by one fp32 re-association each); every other segment is summed by one rank and the all-reduce adds zeros."""
+    n_seg: int              # heavy segments of the whole graph
+    seg_key: Tensor         # int64 [n_seg], ascending: relation * n_nodes + scatter node
+    edge_mask: Tensor       # bool [E]: the edge belongs to a heavy segment (it leaves every rank's light units)
+    n_rows: int             # heavy rows of the whole graph
+    row_lo: int             # this rank's share of the sorted rows: [row_lo, row_hi)
+    row_hi: int
+    seg_lo: int             # first segment the share touches
+    levels: list            # [(seg_ptr int32, seg_idx int32 or None, seg_w float32 or None, n_out)] over the share; outputs = H[seg_lo : seg_lo + n_out]
+
+
+def build_shared_heavy(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes: int, threshold: int, world: int, rank: int,
+                       piece: int = PIECE) -> Optional[SharedHeavy]:
+    """gather / scatter / rel / w: the WHOLE edge list of one direction (replicated on every rank: every rank derives the same
+    segments and the same shares)."""
+    hm = heavy_mask(scatter, rel, n_nodes, threshold)
+    if hm is None:
+        return None
+    g, sc, r_, w_ = gather[hm].to(torch.int64), scatter[hm].to(torch.int64), rel[hm].to(torch.int64), w[hm]
+    key = r_ * n_nodes + sc
+    ukey, seg = torch.unique(key, return_inverse=True)
+    n_seg = int(ukey.shape[0])
+    order = torch.sort(seg * n_nodes + g)[1]                    # rows by (segment, gathered row)
+    m = int(order.shape[0])
+    lo, hi = m * rank // world, m * (rank + 1) // world
+    seg_sorted = seg[order]
+    levels, seg_lo = [], 0
+    if hi > lo:
+        seg_lo = int(seg_sorted[lo])
+        cnt = torch.bincount(seg_sorted[lo:hi] - seg_lo)
+        idx0 = g[order[lo:hi]].to(torch.int32)
+        w0 = w_[order[lo:hi]].to(torch.float32)
+        lv = segment_levels(cnt, piece)
+        levels = [(p.to(torch.int32), idx0 if i == 0 else None, w0 if i == 0 else None, n) for i, (p, n) in enumerate(lv)]
+    return SharedHeavy(n_seg=n_seg, seg_key=ukey, edge_mask=hm, n_rows=m, row_lo=lo, row_hi=hi, seg_lo=seg_lo, levels=levels)
+
+
+def _pseudo_units(prel: Tensor, pdst: Tensor, psrc: Tensor, n_gather_rows: int, n_own: int, num_relations: int):
+    """one pseudo row per heavy segment, relation-major in dense units (sequential placement): prel / pdst (row inside the owned
+    range) / psrc (row of H) per segment, sorted by (relation, destination)"""
+    dev = prel.device
+    n_seg = int(prel.shape[0])
+    r1 = num_relations + 1
+    rcnt = torch.bincount(prel, minlength=r1)
+    runits = (rcnt + UNIT - 1) // UNIT
+    ubase = torch.cumsum(runits, 0) - runits
+    rstart = torch.cumsum(rcnt, 0) - rcnt
+    n_units = int(runits.sum())
+    slot = ubase[prel] * UNIT + (torch.arange(n_seg, device=dev) - rstart[prel])
+    slot_src = torch.full((n_units * UNIT,), n_gather_rows, dtype=torch.int32, device=dev)
+    slot_w = torch.zeros(n_units * UNIT, dtype=torch.float32, device=dev)
+    slot_row = torch.full((n_units * UNIT,), n_own, dtype=torch.int32, device=dev)
+    slot_src[slot] = psrc.to(torch.int32)
+    slot_w[slot] = 1.0
+    slot_row[slot] = pdst.to(torch.int32)
+    unit_rel = torch.repeat_interleave(torch.arange(r1, device=dev), runits).to(torch.int32)
+    uidx = torch.arange(n_units, device=dev) - ubase[unit_rel.long()]
+    used = torch.clamp(rcnt[unit_rel.long()] - uidx * UNIT, max=UNIT)
+    unit_cnt = ((used + 15) // 16 * 16).to(torch.int32)
+    return n_units, unit_rel, unit_cnt, slot_src, slot_w, slot_row
+
+
+def shared_heavy_part(shared: SharedHeavy, n_nodes: int, node_begin: int, node_end: int, num_relations: int) -> Optional[HeavyPart]:
+    """the pseudo rows of the shared segments whose node lies in [node_begin, node_end): they gather rows of the all-reduced H"""
+    node = shared.seg_key % n_nodes
+    mine = torch.nonzero((node >= node_begin) & (node < node_end)).squeeze(1)      # ascending: (relation, node) order
+    if mine.numel() == 0:
+        return None
+    prel = (shared.seg_key[mine] // n_nodes).to(torch.int64)
+    n_units, unit_rel, unit_cnt, slot_src, slot_w, slot_row = _pseudo_units(prel, node[mine] - node_begin, mine, shared.n_seg,
+                                                                             node_end - node_begin, num_relations)
+    return HeavyPart(n_seg=shared.n_seg, levels=[], n_units=n_units, unit_rel=unit_rel, unit_cnt=unit_cnt, slot_src=slot_src,
+                     slot_w=slot_w, slot_row=slot_row, shared=shared)
 
 
 @dataclass
@@ -185,23 +273,8 @@ def build_heavy_part(gather: Tensor, loc: Tensor, rel: Tensor, w: Tensor, n_own:
     # one pseudo row per segment, relation-major in dense units (sequential placement)
     prel = ukey // max(n_own, 1)
     pdst = ukey % max(n_own, 1)
-    r1 = num_relations + 1
-    rcnt = torch.bincount(prel, minlength=r1)
-    runits = (rcnt + UNIT - 1) // UNIT
-    ubase = torch.cumsum(runits, 0) - runits
-    rstart = torch.cumsum(rcnt, 0) - rcnt
-    n_units = int(runits.sum())
-    slot = ubase[prel] * UNIT + (torch.arange(n_seg, device=dev) - rstart[prel])
-    slot_src = torch.full((n_units * UNIT,), n_seg, dtype=torch.int32, device=dev)
-    slot_w = torch.zeros(n_units * UNIT, dtype=torch.float32, device=dev)
-    slot_row = torch.full((n_units * UNIT,), n_own, dtype=torch.int32, device=dev)
-    slot_src[slot] = torch.arange(n_seg, device=dev, dtype=torch.int32)
-    slot_w[slot] = 1.0
-    slot_row[slot] = pdst.to(torch.int32)
-    unit_rel = torch.repeat_interleave(torch.arange(r1, device=dev), runits).to(torch.int32)
-    uidx = torch.arange(n_units, device=dev) - ubase[unit_rel.long()]
-    used = torch.clamp(rcnt[unit_rel.long()] - uidx * UNIT, max=UNIT)
-    unit_cnt = ((used + 15) // 16 * 16).to(torch.int32)
+    n_units, unit_rel, unit_cnt, slot_src, slot_w, slot_row = _pseudo_units(prel, pdst, torch.arange(n_seg, device=dev), n_seg, n_own,
+                                                                             num_relations)
     return HeavyPart(n_seg=n_seg, levels=levels, n_units=n_units, unit_rel=unit_rel, unit_cnt=unit_cnt, slot_src=slot_src,
                      slot_w=slot_w, slot_row=slot_row)
 
@@ -227,7 +300,8 @@ def _finish_levels(slot_row_light: Tensor, heavy: Optional[HeavyPart], n_own: in
 
 
 def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes: int, num_relations: int,
-                    node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE, heavy: int = 0) -> EdgePlan:
+                    node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE, heavy: int = 0,
+                    shared: Optional[SharedHeavy] = None) -> EdgePlan:
     """gather / scatter: int64 [E] node ids (forward: src / dst; transposed: dst / src); w: the edge weights of
     plan.edge_weights (1 / max(1, c[dst, rel]) for aggr = 'mean'), kept for both directions.  heavy: segments of at least
     that many rows are aggregated before the transform (HeavyPart); 0: every row goes through the transform."""
@@ -242,11 +316,14 @@ def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_n
     if gather.numel() and (int(gather.min()) < 0 or int(gather.max()) >= n_nodes
                            or int(scatter.min()) < 0 or int(scatter.max()) >= n_nodes):
         raise ValueError("edge_index out of range [0, num_nodes)")
+    if shared is not None:      # the whole graph's heavy segments, their rows dealt over the ranks (SharedHeavy): not this plan's rows
+        keep_ = ~shared.edge_mask
+        gather, scatter, rel, w = gather[keep_], scatter[keep_], rel[keep_], w[keep_]
     own = (scatter >= node_begin) & (scatter < node_end)
     if not bool(own.all()):
         gather, scatter, rel, w = gather[own], scatter[own], rel[own], w[own]
-    hp = None
-    hm = heavy_mask(scatter, rel, n_nodes, heavy)
+    hp = shared_heavy_part(shared, n_nodes, node_begin, node_end, num_relations) if shared is not None else None
+    hm = heavy_mask(scatter, rel, n_nodes, heavy) if shared is None else None
     if hm is not None:
         hp = build_heavy_part(gather[hm], scatter[hm] - node_begin, rel[hm], w[hm], n_own, num_relations, piece)
         gather, scatter, rel, w = gather[~hm], scatter[~hm], rel[~hm], w[~hm]
@@ -297,7 +374,8 @@ def build_edge_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_n
 
 def build_edge_plan_device(graph, w: Tensor, transposed: bool, n_nodes: int, num_relations: int, ws: Tensor,
                            node_begin: int = 0, node_end: Optional[int] = None, piece: int = PIECE, heavy: int = 0,
-                           edge_index: Optional[Tensor] = None, edge_type: Optional[Tensor] = None) -> EdgePlan:
+                           edge_index: Optional[Tensor] = None, edge_type: Optional[Tensor] = None,
+                           shared: Optional[SharedHeavy] = None, light_graph=None) -> EdgePlan:
     """The same plan by the library's own builder (csrc/rgcn_plan.hip): rgcn_plan_build_begin / _finish with layout 2 lay the
     owned range out as one relation-major "tile", rgcn_eplan_segments sorts the slots by destination; only the sum levels of
     hubs (arithmetic on seg_ptr) and the split-off of the heavy segments (``heavy`` > 0; needs the COO tensors) stay here.
@@ -307,7 +385,12 @@ def build_edge_plan_device(graph, w: Tensor, transposed: bool, n_nodes: int, num
         node_end = n_nodes
     n_own = node_end - node_begin
     hp, keep = None, None
-    if heavy > 0 and edge_index is not None and int(edge_type.shape[0]) > 0:
+    if shared is not None:
+        # hubs split across ranks: the light graph (the edge list without the whole graph's heavy segments; built once per
+        # direction by the caller: light_graph = (graph struct, its weights)) and the pseudo rows of this range's segments
+        graph, w = light_graph
+        hp = shared_heavy_part(shared, n_nodes, node_begin, node_end, num_relations)
+    elif heavy > 0 and edge_index is not None and int(edge_type.shape[0]) > 0:
         g_, s_ = (edge_index[1], edge_index[0]) if transposed else (edge_index[0], edge_index[1])
         own = (s_ >= node_begin) & (s_ < node_end)
         hm = heavy_mask(torch.where(own, s_, torch.full_like(s_, -1)), edge_type, n_nodes + 1, heavy)      # (-1: not owned, its own keys)

@@ -608,13 +608,15 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
                              bwd_range: Optional[Tuple[int, int]] = None, chunk: int = CHUNK,
                              ranges=None, split: bool = False, dw_tiles: bool = False,
                              paths: Tuple[str, str] = ("ring", "ring"), rank_dw_range: Optional[Tuple[int, int]] = None,
-                             extras: Optional[dict] = None):
+                             extras: Optional[dict] = None, hub_split: Optional[Tuple[int, int]] = None):
     """The plans built by the HIP library itself (csrc/rgcn_plan.hip through rgcn_edge_weights / rgcn_plan_build_*):
     what every GPU forward uses.  ``ranges``: a list of (begin, end) owned ranges -> a list of GraphPlans that share one
     edge-weight pass and one workspace (dist.py: one pair of plans per owned block).  ``rank_dw_range`` (dist.py, full exchange):
     ONE tile-major weight-gradient plan over that contiguous node range besides the pieces' forward / transposed plans, returned
     in ``extras["dw_rank"] = (plan, walk table)`` -- both operands of d_weight are replicated, so its cut need not be the
-    forward's and one launch per rank replaces one per piece."""
+    forward's and one launch per rank replaces one per piece.  ``hub_split = (world, rank)`` (dist.py): the heavy segments of an
+    edge-parallel direction are the WHOLE graph's, their rows dealt over the ranks (eplan.SharedHeavy, returned in
+    ``extras["shared_fwd"]`` / ``["shared_bwd"]``); the pieces' plans hold the light rows and the pseudo rows of their own segments."""
     from . import _lib
     if chunk not in CHUNKS:
         raise ValueError(f"chunk must be one of {CHUNKS}")
@@ -632,6 +634,23 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
         raise
     from .eplan import HEAVY
     heavy = HEAVY
+    shared, light, keep_light = [None, None], [None, None], []
+    if hub_split is not None and e > 0:
+        from .eplan import build_shared_heavy
+        for d in (0, 1):
+            if paths[d] != "ep":
+                continue
+            g_, s_ = (edge_index[1], edge_index[0]) if d else (edge_index[0], edge_index[1])
+            sh = build_shared_heavy(g_, s_, edge_type, w, n_nodes, heavy, hub_split[0], hub_split[1])
+            if sh is None:
+                continue
+            lm = ~sh.edge_mask
+            ei_l, et_l, w_l = edge_index[:, lm].contiguous(), edge_type[lm].contiguous(), w[lm].contiguous()
+            g_l, k_l = _lib.graph_struct(ei_l, et_l, n_nodes, num_relations)
+            keep_light.append((k_l, ei_l, et_l))
+            shared[d], light[d] = sh, (g_l, w_l)
+        if extras is not None:
+            extras["shared_fwd"], extras["shared_bwd"] = shared
     out = []
     for (fb, fe), (bb, be) in rs:
         gp = GraphPlans(fwd=None, bwd=None, num_edges=e)
@@ -642,7 +661,7 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
         if paths[0] == "ep":       # edge-parallel direction: relation-major units + destination-major segments (eplan.py)
             from .eplan import build_edge_plan_device
             gp.ep_fwd = build_edge_plan_device(graph, w, False, n_nodes, num_relations, ws, fb, fe, heavy=heavy,
-                                               edge_index=edge_index, edge_type=edge_type)
+                                               edge_index=edge_index, edge_type=edge_type, shared=shared[0], light_graph=light[0])
         else:
             gp.fwd = _device_plan(graph, w, False, n_nodes, num_relations, tile, chunk, fb, fe, ws, split)
             if ranges is not None:
@@ -650,7 +669,7 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
         if paths[1] == "ep":
             from .eplan import build_edge_plan_device
             gp.ep_bwd = build_edge_plan_device(graph, w, True, n_nodes, num_relations, ws, bb, be, heavy=heavy,
-                                               edge_index=edge_index, edge_type=edge_type)
+                                               edge_index=edge_index, edge_type=edge_type, shared=shared[1], light_graph=light[1])
         else:
             gp.bwd = _device_plan(graph, w, True, n_nodes, num_relations, tile, chunk, bb, be, ws, split)
         if dw_tiles and paths[0] != "ep" and fe > fb:
@@ -669,7 +688,7 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
                 extras["dw_rank"] = (pl, _lib.dw_tiles_walk(_lib.plan_struct(pl), edge_type.device))
             else:
                 extras["dw_rank"] = (None, None)      # an empty range (fewer tiles than ranks): this rank adds zeros
-    del keep
+    del keep, keep_light
     return out if ranges is not None else out[0]
 
 

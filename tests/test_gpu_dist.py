@@ -61,7 +61,7 @@ def _worker(rank, world, port, ret, dw_direct):
             conv.root.copy_(root)
             conv.bias.copy_(bias + 0.25)
         if partitioned:
-            rdist.attach(conv, n, e, edge_index=ei, exchange="needed" if needed else "full")
+            rdist.attach(conv, n, e, edge_index=ei, exchange="needed" if needed else "full", edge_type=et)
             assert conv.dist is not None and conv.dist.world == world
             assert conv.dist.uniform == (not skew)
             conv.dist.poison_unread = needed
@@ -94,6 +94,13 @@ def _worker(rank, world, port, ret, dw_direct):
             pl = conv._plans(xd, ei.to(dev), et.to(dev))
             pcs = pl.pieces if partitioned else [pl]
             assert all(pc.ep_fwd is not None for pc in pcs if pc.fwd is None) and any(pc.ep_fwd is not None for pc in pcs)
+            if partitioned:      # hubs split across ranks: the heavy segments of the whole graph, an equal share of their rows per rank
+                sh = pl.shared_fwd
+                assert sh is not None and sh.n_seg > 0 and 0 < sh.row_hi - sh.row_lo <= sh.n_rows // world + 1
+                assert all(pc.ep_fwd.heavy is None or pc.ep_fwd.heavy.shared is sh for pc in pcs)
+                assert conv.dist.stats.get("shared_heavy_rows", 0) >= sh.row_hi - sh.row_lo
+                bc = conv.dist.block_costs.sum(0) + conv.dist.shared_rows_per_rank
+                assert float(bc.max() / bc.mean()) <= 1.3, "rows walked per rank max / mean with the hubs split across the ranks"
         return (out.detach().cpu().numpy(), xd.grad.cpu().numpy(), conv.weight.grad.cpu().numpy(),
                 conv.root.grad.cpu().numpy(), conv.bias.grad.cpu().numpy())
 
