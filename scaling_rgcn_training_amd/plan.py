@@ -31,6 +31,7 @@ without atomics").  Everything here is torch tensor plumbing and runs on CPU or 
 """
 from __future__ import annotations
 
+import functools
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
@@ -458,6 +459,13 @@ P3_MAX_TILE = 224          # rgcn_tile3p_kernel: two 48 KiB ring slots + the fp3
 
 def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int, kernel: str = "fp32",
                   with_cost: bool = False):
+    """cached front of ``_choose_layout`` (a layer asks on every forward call; the model is a few hundred erfc evaluations)"""
+    return _choose_layout(int(n_nodes), int(n_edges), int(num_relations), int(in_channels), int(out_channels), kernel, bool(with_cost))
+
+
+@functools.lru_cache(maxsize=256)
+def _choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int, kernel: str = "fp32",
+                   with_cost: bool = False):
     """(tile, chunk) for a layer: output nodes per tile and edge slots per chunk.  ``kernel="bf16x3"``: the layout for
     rgcn_tile3p_kernel (64 x 64 layers: 128-slot chunks, tiles up to 224, its own per-chunk / per-row-tile cycles);
     ``with_cost``: also the modelled time of one launch, comparable between the two kernels (conv.RGCNConv.layout picks with it).
