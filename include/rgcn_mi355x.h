@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 16
+#define RGCN_ABI_VERSION 17
 #define RGCN_UNIT 64 /* edge slots per unit of the weight-gradient walk (rel_order); a chunk is 1 or 2 units */
 #define RGCN_CHUNK_MAX 128 /* plan->chunk is 64 or 128 edge slots (rows of one LDS ring slot of the forward / dX kernel) */
 #define RGCN_MAX_WIDTH 128
@@ -96,7 +96,9 @@ typedef struct rgcn_plan {
                             * weight" (a shadow slot's slot_acc then holds the float weight / head's weight).  Walked by rgcn_fwd / rgcn_bwd_dx with RGCN_FLAG_SPLIT_PRODUCERS on 64 x 64 layers only (the
                             * producer waves add a run's rows before they cut them: aggregate, then transform); every other
                             * entry point answers RGCN_ERR_PLAN */
-    int32_t reserved;
+    int32_t chunk_rows;    /* rows a chunk may hold: = chunk, or 112 (chunk = 128: seven row tiles of rows, the eighth free for shadow
+                            * rows; built by rgcn_plan_build_begin(chunk = 112)): what rgcn_tile3p_kernel's 42 KiB ring slots hold,
+                            * which leaves its accumulator room for tiles up to 272.  0 is read as `chunk` */
     const int32_t* tile_ptr;   /* [n_tiles + 1] tile-major chunk ranges */
     const int32_t* chunk_rel;  /* [n_chunks] relation id, R' for root chunks */
     const int32_t* chunk_cnt;  /* [n_chunks] slots of the chunk's used 16-slot MFMA row tiles (16, 32, ... chunk);
@@ -160,7 +162,8 @@ int rgcn_edge_weights(const rgcn_graph_t* graph, int aggr_sum, float* w, void* w
  * _begin sorts, merges duplicate triples and sizes the plan (SYNCHRONISES the stream: the sizes are data-dependent);
  * the caller then allocates the ten device arrays of `plan` (sizes above; nothing in this library allocates) and
  * _finish fills them and the scalar fields, asynchronously on `stream`.  tile: output nodes per tile (multiple of
- * 16), chunk: 64 or 128, layout: 0, 2 (chunk = 64) or (chunk = 128) 1 / 3, see struct rgcn_plan.  Replaces scaling_rgcn_training_amd/plan.py (torch tensor ops), which stays as the test
+ * 16), chunk: 64 or 128 -- or 112 (layouts 0 and 3): a plan of 128-slot chunks that hold at most 112 rows, see rgcn_plan.chunk_rows --,
+ * layout: 0, 2 (chunk = 64) or (chunk = 128) 1 / 3, see struct rgcn_plan.  Replaces scaling_rgcn_training_amd/plan.py (torch tensor ops), which stays as the test
  * oracle: all arrays are bit-identical. */
 int rgcn_plan_build_begin(const rgcn_graph_t* graph, const float* w, int transposed, int32_t node_begin, int32_t node_end,
                           int32_t tile, int32_t chunk, int32_t layout, void* workspace, size_t workspace_bytes,

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGCN_LIB: an alternative build of the same library (kernel experiments: tools/debug/)
 LIB_PATH = os.environ.get("RGCN_LIB") or os.path.join(_HERE, "librgcn_mi355x.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EXPORTS = (
     "rgcn_abi_version", "rgcn_status_string", "rgcn_padded_width", "rgcn_packed_weight_floats",
@@ -37,7 +37,7 @@ class RgcnPlanStruct(C.Structure):
     _fields_ = [
         ("n_nodes", C.c_int32), ("n_owned", C.c_int32), ("num_relations", C.c_int32),
         ("tile", C.c_int32), ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("chunk", C.c_int32), ("n_units", C.c_int32),
-        ("layout", C.c_int32), ("reserved", C.c_int32),
+        ("layout", C.c_int32), ("chunk_rows", C.c_int32),
         ("tile_ptr", C.c_void_p), ("chunk_rel", C.c_void_p), ("chunk_cnt", C.c_void_p),
         ("chunk_tile", C.c_void_p), ("chunk_flags", C.c_void_p), ("rel_order", C.c_void_p), ("slot_src", C.c_void_p),
         ("slot_w", C.c_void_p), ("slot_row", C.c_void_p), ("slot_acc", C.c_void_p),
@@ -168,7 +168,7 @@ def plan_struct(plan) -> RgcnPlanStruct:
         raise RgcnLibraryError("the graph plan must live on the GPU (plan tensors are on %s)" % plan.slot_src.device)
     plan._cstruct = RgcnPlanStruct(
         plan.n_nodes, plan.n_owned, plan.num_relations, plan.tile, plan.n_tiles, plan.n_chunks, plan.chunk, plan.n_units,
-        int(getattr(plan, "layout", 0)), 0,
+        int(getattr(plan, "layout", 0)), int(getattr(plan, "chunk_rows", 0) or plan.chunk),
         plan.tile_ptr.data_ptr(), plan.chunk_rel.data_ptr(), plan.chunk_cnt.data_ptr(),
         plan.chunk_tile.data_ptr(), plan.chunk_flags.data_ptr(), plan.rel_order.data_ptr(), plan.slot_src.data_ptr(),
         plan.slot_w.data_ptr(), plan.slot_row.data_ptr(), plan.slot_acc.data_ptr())

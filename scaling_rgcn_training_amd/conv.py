@@ -580,7 +580,7 @@ class RGCNConv(nn.Module):
         n = x.shape[0]
         e = int(edge_type.shape[0])
         tile, chunk = self.layout(n, e)
-        split = self.team_layout and self._use_split_producers(chunk)       # plan layout 1 (team placement)
+        split = self.team_layout and chunk == 128 and self._use_split_producers(chunk)       # plan layout 1 (team placement)
         # the tile-major weight-gradient kernel: 64 x 64 layers with few relations on graphs large enough to fill it
         # (it gathers through buffer descriptors only: above 2^24 rows / 4 GiB the relation-major kernels run)
         from .plan import padded_width
@@ -612,7 +612,7 @@ class RGCNConv(nn.Module):
         """whether a plan of ``self.layout`` with that chunk runs on the bf16 x 3 kernel (layout() returns 128-slot chunks for a
         64 x 64 layer with split_producers only where that kernel is the modelled choice, at a tile it has room for)"""
         from .plan import padded_width
-        return (self.split_producers and chunk == 128 and not _ENV_TILE
+        return (self.split_producers and chunk in (112, 128) and not _ENV_TILE
                 and padded_width(self.in_channels) == 64 and padded_width(self.out_channels) == 64)
 
     def _exact_merge(self, chunk: int) -> bool:

@@ -343,17 +343,24 @@ __global__ void group_start_kernel(const u64* __restrict__ ukeys, u32 n, int gsh
     }
 }
 
-// chunks and 64-slot units of every group
-__global__ void group_sizes_kernel(const u32* __restrict__ gstart, u32 n_groups, u32 chunk, u32 layout, u32* __restrict__ gch,
+// chunks and 64-slot units of every group.  cap: row tiles a chunk may hold (chunk / 16, or 7 for the 112-row chunks of
+// rgcn_tile3p_kernel's larger tiles: the slot stride stays 128, the eighth row tile of a chunk stays free for shadow rows)
+__global__ void group_sizes_kernel(const u32* __restrict__ gstart, u32 n_groups, u32 chunk, u32 cap, u32 layout, u32* __restrict__ gch,
                                    u32* __restrict__ gun) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const u32 cnt = gstart[g + 1] - gstart[g];
     const u32 nt = (cnt + 15u) / 16u;
-    gch[g] = (cnt + chunk - 1u) / chunk;
-    // both layouts put the rows of a chunk on contiguous row tiles from tile 0 and use ceil(cnt / 16) tiles per group
     (void)layout;
-    gun[g] = (nt + 3u) / 4u;
+    if (cap * 16u == chunk) {
+        gch[g] = (cnt + chunk - 1u) / chunk;
+        // both layouts put the rows of a chunk on contiguous row tiles from tile 0 and use ceil(cnt / 16) tiles per group
+        gun[g] = (nt + 3u) / 4u;
+    } else {      // layout 0 dealing over chunks of `cap` row tiles
+        const u32 full = nt / cap, rem = nt % cap;
+        gch[g] = full + (rem ? 1u : 0u);
+        gun[g] = full * ((cap + 3u) / 4u) + (rem + 3u) / 4u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,7 +382,7 @@ __global__ void fill_slots_kernel(u32 n_slots, u32 n_nodes, u32 tile, int32_t* _
 // Layout 1 (plan.team_placement): chunk c of the group takes its rows [128 c, 128 c + 128) on nt = ceil(n_c / 16) row tiles, cut
 // at split[chunk] into part A (dealt over the first ceil(nt / 2) row tiles) and part B (the others): disjoint destinations.
 __global__ void place_kernel(const u64* __restrict__ ukeys, const u32* __restrict__ uvals, u32 n, const u32* __restrict__ gid,
-                             const u32* __restrict__ gstart, const u32* __restrict__ chunk_base, u32 chunk, u32 layout,
+                             const u32* __restrict__ gstart, const u32* __restrict__ chunk_base, u32 chunk, u32 cap, u32 layout,
                              const u32* __restrict__ split, KeyLayout kl, int32_t* __restrict__ slot_src,
                              float* __restrict__ slot_w, u32* __restrict__ dstl) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -385,8 +392,8 @@ __global__ void place_kernel(const u64* __restrict__ ukeys, const u32* __restric
     const u32 rank = i - s0;
     size_t slot;
     if (layout == 0) {
-        const u32 nt = (cnt + 15u) / 16u;
-        slot = (size_t)chunk_base[g] * chunk + (size_t)(rank % nt) * 16u + rank / nt;
+        const u32 nt = (cnt + 15u) / 16u, t = rank % nt;      // the group's row tile t: chunk t / cap of the group, its row tile t % cap
+        slot = (size_t)(chunk_base[g] + t / cap) * chunk + (size_t)(t % cap) * 16u + rank / nt;
     } else {
         const u32 cidx = rank / 128u, jc = rank % 128u;
         const u32 left = cnt - cidx * 128u, n_c = left < 128u ? left : 128u;
@@ -409,7 +416,7 @@ __global__ void place_kernel(const u64* __restrict__ ukeys, const u32* __restric
 }
 
 __global__ void chunk_meta_kernel(const u32* __restrict__ chunk_base, const u32* __restrict__ gstart, const u32* __restrict__ gkey,
-                                  u32 n_groups, u32 n_chunks, u32 chunk, u32 layout, const u64* __restrict__ ukeys, KeyLayout kl,
+                                  u32 n_groups, u32 n_chunks, u32 chunk, u32 cap, u32 layout, const u64* __restrict__ ukeys, KeyLayout kl,
                                   u32* __restrict__ split, int32_t* __restrict__ chunk_rel, int32_t* __restrict__ chunk_cnt,
                                   int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_flags) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,7 +432,7 @@ __global__ void chunk_meta_kernel(const u32* __restrict__ chunk_base, const u32*
     const u32 idx = c - chunk_base[g];
     int32_t flags = 0;
     if (layout == 0) {
-        const u32 nt = (cnt + 15u) / 16u, per = chunk / 16u;
+        const u32 nt = (cnt + 15u) / 16u, per = cap;
         const u32 left = nt - idx * per;
         chunk_cnt[c] = (int32_t)((left < per ? left : per) * 16u);
     } else {
@@ -724,6 +731,7 @@ static int check_graph(const rgcn_graph_t* g) {
 struct BuildState {
     u32 magic;
     u32 n_nodes, n_own, node_begin, num_rel, tile, chunk, layout;
+    u32 cap;                // row tiles a chunk may hold (chunk / 16; 7: 112-row chunks at a 128-slot stride)
     u32 n_unique, n_groups, n_chunks, n_units, n_edges_owned;
     u32 ubuf;               // index of the SortBufs pair holding the merged (key, weight) arrays
     u64 nmax, gmax;
@@ -788,6 +796,14 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     int st = check_graph(g);
     if (st != RGCN_OK) return st;
     if (!sizes || !workspace || (g->num_edges > 0 && !w)) return RGCN_ERR_NULL;
+    // chunk = 112: the slot stride of 128-slot chunks with at most SEVEN row tiles of rows per chunk (layouts 0 and 3) -- what
+    // rgcn_tile3p_kernel's 42 KiB ring slots hold, which leaves its accumulator room for tiles up to 272
+    u32 cap = (u32)chunk / 16u;
+    if (chunk == 112) {
+        if (layout != 0 && layout != 3) return RGCN_ERR_PLAN;
+        cap = 7u;
+        chunk = 128;
+    }
     if (layout == 2) {
         // relation-major units (the edge-parallel path, rgcn_ep_*): ONE tile that spans the owned range makes the key order
         // (tile, relation, row, gathered node) relation-major; the rows of a relation are dealt over its row tiles as in layout 0
@@ -847,7 +863,7 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     if ((u64)n_groups + 1 > gmax) return RGCN_ERR_PLAN;
     hipLaunchKernelGGL(group_start_kernel, dim3(grid_for(n_unique)), dim3(256), 0, s, ws.sb.k[ub], n_unique, kl.gshift(), ws.scan_b,
                        ws.gstart, ws.gkey, n_groups);
-    hipLaunchKernelGGL(group_sizes_kernel, dim3(grid_for(n_groups)), dim3(256), 0, s, ws.gstart, n_groups, (u32)chunk, (u32)layout, ws.gch, ws.gun);
+    hipLaunchKernelGGL(group_sizes_kernel, dim3(grid_for(n_groups)), dim3(256), 0, s, ws.gstart, n_groups, (u32)chunk, cap, (u32)layout, ws.gch, ws.gun);
     u32 n_chunks = 0, n_units = 0;
     exclusive_scan(ws.gun, ws.gun, n_groups, ws.sb.sums, s);
     if ((st = read_u32(ws.sb.sums + scan_blocks(n_groups), &n_units, s)) != 0) return st;
@@ -865,7 +881,7 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
     memset(&bs, 0, sizeof(bs));
     bs.magic = kMagic;
     bs.n_nodes = (u32)g->num_nodes; bs.n_own = n_own; bs.node_begin = (u32)node_begin; bs.num_rel = R;
-    bs.tile = (u32)tile; bs.chunk = (u32)chunk; bs.layout = (u32)layout;
+    bs.tile = (u32)tile; bs.chunk = (u32)chunk; bs.layout = (u32)layout; bs.cap = cap;
     bs.n_unique = n_unique; bs.n_groups = n_groups; bs.n_chunks = n_chunks; bs.n_units = n_units; bs.n_edges_owned = owned;
     bs.ubuf = (u32)ub; bs.nmax = nmax; bs.gmax = gmax; bs.kl = kl;
     memcpy(sizes->opaque, &bs, sizeof(bs));
@@ -899,9 +915,9 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     // relation-major units: layout 0's dealing inside the one tile; layout 3: layout 0, then compact_runs_kernel
     const u32 placement = (bs.layout == 2 || bs.layout == 3) ? 0u : bs.layout;
     hipLaunchKernelGGL(chunk_meta_kernel, dim3(grid_for(bs.n_chunks)), dim3(256), 0, s, ws.gch, ws.gstart, ws.gkey, bs.n_groups,
-                       bs.n_chunks, bs.chunk, placement, ws.sb.k[bs.ubuf], bs.kl, split, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
+                       bs.n_chunks, bs.chunk, bs.cap, placement, ws.sb.k[bs.ubuf], bs.kl, split, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
     hipLaunchKernelGGL(place_kernel, dim3(grid_for(bs.n_unique)), dim3(256), 0, s, ws.sb.k[bs.ubuf], ws.sb.v[bs.ubuf], bs.n_unique,
-                       ws.scan_b, ws.gstart, ws.gch, bs.chunk, placement, split, bs.kl, slot_src, slot_w, dstl);
+                       ws.scan_b, ws.gstart, ws.gch, bs.chunk, bs.cap, placement, split, bs.kl, slot_src, slot_w, dstl);
     hipLaunchKernelGGL(row_tile_kernel, dim3(grid_for(n_rt)), dim3(256), 0, s, dstl, n_rt, bs.chunk, bs.tile, bs.n_own, chunk_tile,
                        slot_acc, slot_row, chunk_flags);
     const u32 struct_tile = bs.layout == 2 ? (bs.tile < 32768u ? bs.tile : 32768u) : bs.tile;
@@ -931,6 +947,7 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     plan->chunk = (int32_t)bs.chunk;
     plan->n_units = (int32_t)bs.n_units;
     plan->layout = (int32_t)bs.layout;
+    plan->chunk_rows = (int32_t)(bs.cap * 16u);
     return (int)hipGetLastError();
 }
 

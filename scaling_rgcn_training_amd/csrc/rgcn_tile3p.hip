@@ -79,9 +79,17 @@ __device__ __forceinline__ unsigned long long p3_stamp() {
 #endif
 
 constexpr int kP3Threads = 512;                          // 4 producer + 4 consumer waves
-constexpr int kP3CH = 128;                               // rows of a ring slot == plan chunk
-constexpr int kP3PlaneBytes = kP3CH * 128;               // one bf16 plane of a slot
-constexpr int kP3SlotBytes = 3 * kP3PlaneBytes;
+constexpr int kP3CH = 128;                               // slots of a plan chunk (stride of the plan's slot arrays)
+// Row tiles a ring slot has room for (template parameter ST of the kernel).  8: any 128-slot chunk (48 KiB slots: tiles up to
+// 224).  7 (round 4): plans whose chunks hold at most 112 rows (rgcn_plan.chunk_rows; the shadow row tiles of a layout-3 chunk
+// never reach LDS) -- 42 KiB slots leave the accumulator room for tiles up to 272: 18 % fewer chunks at the headline config.
+// Timing-only builds with clamped chunks (profiles/r04k_*, r04l_*: -DRGCN_P3_SLOT_TILES_EXPERIMENT=6 / 7) priced it first:
+// 7 tiles at T = 272: 7.80 / 7.89 ms against 8.27 / 8.30; 6 tiles at T = 304 / 320: 7.80 / 7.75.
+template <int ST>
+struct P3Geo {
+    static constexpr int kPlaneBytes = 16 * ST * 128;       // one bf16 plane of a slot
+    static constexpr int kSlotBytes = 3 * kPlaneBytes;
+};
 constexpr int kP3LDO = kAccStride<64>;
 constexpr int kP3FragsPerRel = 2 * 3 * 2 * 2;            // rgcn_pack3_kernel: [column half c][plane][column tile ct][k-step s]
 
@@ -134,8 +142,10 @@ __device__ __forceinline__ void p3_wait_batch(P3Rows& r) {
                  : "memory");
 }
 
+template <int ST>
 __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, float* wring, int* dring, int c0, int nch,
                                                  int lane, int pw, int tile0) {
+    constexpr int kP3PlaneBytes = P3Geo<ST>::kPlaneBytes, kP3SlotBytes = P3Geo<ST>::kSlotBytes, kP3SlotTiles = ST;
     // c0 / nch: the chunks of ALL the tiles the workgroup walks, one sequence for the ring; where a chunk closes a tile the
     // consumers store and reset the accumulator: the producers join one extra barrier there (equal barrier counts)
     int tile_cur = tile0;
@@ -270,7 +280,7 @@ __device__ __forceinline__ void p3_producer_loop(const TileArgs& a, char* ring, 
     // one scalar word per chunk, fetched an iteration ahead: the chunk's slot count, or on a layout-3 plan its flags, whose bits
     // 20-23 repeat the row-tile count (compact_runs_kernel) beside the shadow counts
     auto word_of = [&](int k) { return ldc(a.merged ? a.chunk_flags : a.chunk_cnt, c0 + (k < nch ? k : nch - 1)); };
-    auto tiles_in = [&](int wd) { return a.merged ? (wd >> 20) & 15 : (wd + 15) >> 4; };
+    auto tiles_in = [&](int wd) { return min(kP3SlotTiles, a.merged ? (wd >> 20) & 15 : (wd + 15) >> 4); };
     auto flags_in = [&](int wd) { return a.merged ? wd : 0; };
     // (the consumers fetch their per-chunk words through scalar BUFFER loads with one running offset; the same change here does
     // not compile -- the backend reports an illegal VGPR-to-SGPR copy on the loop-carried word -- and the producers are not the
@@ -335,8 +345,9 @@ struct P3Cfg {
     static constexpr int kWavesPerSimd = (4 + kConsumers) / 4;
 };
 
-template <int TEAMS, int NCT>
+template <int TEAMS, int NCT, int ST>
 __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, NCT>::kWavesPerSimd)) rgcn_tile3p_kernel(const TileArgs a) {
+    constexpr int kP3PlaneBytes = P3Geo<ST>::kPlaneBytes, kP3SlotBytes = P3Geo<ST>::kSlotBytes, kP3SlotTiles = ST;
     constexpr int LDO = kP3LDO;
     constexpr int kThreadsAll = P3Cfg<TEAMS, NCT>::kThreads;
     constexpr int kConsumers = P3Cfg<TEAMS, NCT>::kConsumers;
@@ -438,7 +449,7 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
             moff += 4;
             (void)chunk;
             const bool swap_b = pending;
-            const int nrt = (cnt + 15) >> 4;
+            const int nrt = min(kP3SlotTiles, (cnt + 15) >> 4);
             // this wave's row tiles of the chunk: [t0, t0 + n)
             int t0 = 0, n = nrt;
             bool serial = false;                // a chunk whose parts share a destination: team A takes all of it, tile by tile
@@ -616,7 +627,7 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
                     case 5: if constexpr (TEAMS == 1) consume(integral_constant<int, 5>{}); break;
                     case 6: if constexpr (TEAMS == 1) consume(integral_constant<int, 6>{}); break;
                     case 7: if constexpr (TEAMS == 1) consume(integral_constant<int, 7>{}); break;
-                    case 8: if constexpr (TEAMS == 1) consume(integral_constant<int, 8>{}); break;
+                    case 8: if constexpr (TEAMS == 1 && ST >= 8) consume(integral_constant<int, 8>{}); break;
                     default: break;
                 }
             } else {
@@ -667,13 +678,13 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
 #endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the consumers is pending when the producer code follows
     }
-    if (!is_consumer) p3_producer_loop(a, ring, wring, dring, c0, nch, lane, role_idx, tile0);
+    if (!is_consumer) p3_producer_loop<ST>(a, ring, wring, dring, c0, nch, lane, role_idx, tile0);
     tile_epilogue<LDO, false>(a, out_lds, tile1 - 1, tid, kThreadsAll);
 }
 
-// bytes of dynamic LDS at tile size `tile`
-static size_t p3_lds_bytes(int tile) {
-    return sizeof(float) * (size_t)(tile + 1) * kP3LDO + 2 * (size_t)kP3SlotBytes + 2 * kP3CH * 8;
+// bytes of dynamic LDS at tile size `tile` with ring slots of `st` row tiles
+static size_t p3_lds_bytes(int tile, int st) {
+    return sizeof(float) * (size_t)(tile + 1) * kP3LDO + 2 * (size_t)(3 * 16 * st * 128) + 2 * kP3CH * 8;
 }
 
 // Launch (called by run_tile in rgcn_tile_fp32.hip when RGCN_FLAG_SPLIT_PRODUCERS is set and the shapes fit): `a.wp` points at
@@ -692,7 +703,7 @@ static size_t p3_lds_bytes(int tile) {
 #ifndef RGCN_P3_TEAMS        // 2: layout-1 plans run the two-team kernel
 #define RGCN_P3_TEAMS 1
 #endif
-template <int TEAMS, int NCT>
+template <int TEAMS, int NCT, int ST>
 static int launch_tile3p_as(const TileArgs& b, int nwg, size_t lds, hipStream_t stream) {
     static std::atomic<unsigned long long> done{0};
     int dev = 0;
@@ -700,17 +711,19 @@ static int launch_tile3p_as(const TileArgs& b, int nwg, size_t lds, hipStream_t 
     if (e != hipSuccess) return (int)e;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute((const void*)rgcn_tile3p_kernel<TEAMS, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        e = hipFuncSetAttribute((const void*)rgcn_tile3p_kernel<TEAMS, NCT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int)e;
         done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((rgcn_tile3p_kernel<TEAMS, NCT>), dim3(nwg), dim3(P3Cfg<TEAMS, NCT>::kThreads), lds, stream, b);
+    hipLaunchKernelGGL((rgcn_tile3p_kernel<TEAMS, NCT, ST>), dim3(nwg), dim3(P3Cfg<TEAMS, NCT>::kThreads), lds, stream, b);
     return (int)hipGetLastError();
 }
 
-int launch_tile3p(const TileArgs& a, int n_tiles, int layout, void* stream) {
+int launch_tile3p(const TileArgs& a, int n_tiles, int layout, int chunk_rows, void* stream) {
     if (a.x_bytes == 0) return RGCN_ERR_PLAN;          // buffer-descriptor addressing only
-    const size_t lds = p3_lds_bytes(a.tile);
+    // plans whose chunks hold at most 112 rows run on 42 KiB ring slots (tiles up to 272), any other 128-slot plan on 48 KiB ones
+    const int st = chunk_rows > 0 && chunk_rows <= 112 ? 7 : 8;
+    const size_t lds = p3_lds_bytes(a.tile, st);
     if (lds > (size_t)kLdsBytes) return RGCN_ERR_LDS;
     // walking several tiles pays once every CU gets many workgroups either way (start-up: two trips to memory per workgroup);
     // on graphs of a few launch rounds one tile per workgroup balances better (300k nodes / 1,340 tiles: 4.28 against 4.44 ms)
@@ -718,8 +731,9 @@ int launch_tile3p(const TileArgs& a, int n_tiles, int layout, void* stream) {
     if (n_tiles < 16 * 256) b.tiles_per_wg = 1;
     const int nwg = (n_tiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
     if constexpr (RGCN_P3_TEAMS == 2)
-        if (layout == 1) return launch_tile3p_as<2, RGCN_P3_NCT>(b, nwg, lds, (hipStream_t)stream);
-    return launch_tile3p_as<1, 1>(b, nwg, lds, (hipStream_t)stream);
+        if (layout == 1) return launch_tile3p_as<2, RGCN_P3_NCT, 8>(b, nwg, lds, (hipStream_t)stream);
+    if (st == 7) return launch_tile3p_as<1, 1, 7>(b, nwg, lds, (hipStream_t)stream);
+    return launch_tile3p_as<1, 1, 8>(b, nwg, lds, (hipStream_t)stream);
 }
 
 #ifdef RGCN_P3_STAMPS

@@ -86,6 +86,6 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, float* out_lds,
 }
 
 // rgcn_tile3p.hip: producer-split bf16 kernel (64 -> 64, 128-slot chunks, buffer-addressable x; layout 1: two consumer teams)
-int launch_tile3p(const TileArgs& a, int n_tiles, int layout, void* stream);
+int launch_tile3p(const TileArgs& a, int n_tiles, int layout, int chunk_rows, void* stream);
 
 }  // namespace rgcn

@@ -75,7 +75,7 @@ static int run_tile(const rgcn_plan_t* plan, const float* x, int ldx, int kin, c
         a.x_bytes != 0) {
         TileArgs b = a;
         b.wp = packed + (size_t)(plan->num_relations + 1) * KP * NP;
-        const int st3 = launch_tile3p(b, plan->n_tiles, plan->layout, stream);
+        const int st3 = launch_tile3p(b, plan->n_tiles, plan->layout, plan->chunk_rows, stream);
         if (st3 != RGCN_ERR_LDS || plan->layout == 3) return st3;
     }
     // layout 3 (runs of equal (destination, relation) on ONE slot, their other rows in shadow row tiles): besides the kernel above

@@ -40,7 +40,10 @@ from torch import Tensor
 
 CHUNK = 64  # default edge slots per chunk == rows of one LDS ring slot (csrc/rgcn_common.h kChunk)
 UNIT = 64   # rows the weight-gradient kernels walk at a time: a chunk is chunk // UNIT units
-CHUNKS = (64, 128)   # chunk sizes the kernels are built for
+CHUNKS = (64, 128)   # chunk sizes (slot strides) the kernels are built for
+CHUNK_112 = 112      # as the ``chunk`` argument of the builders: 128-slot chunks that hold at most SEVEN row tiles (112 rows) of rows
+                     # -- what rgcn_tile3p_kernel's 42 KiB ring slots hold, leaving its accumulator room for tiles up to 272
+                     # (TilePlan.chunk stays 128, TilePlan.chunk_rows says 112)
 
 
 @dataclass
@@ -69,6 +72,7 @@ class TilePlan:
     slot_acc: Tensor      # int32 [n_chunks * chunk]  run-end position << 24 | accumulator row
     layout: int = 0       # 0: rows of a group dealt over all its row tiles; 1: team placement (team_placement);
     #                       3: layout 0 with the runs of equal (destination, relation) on one slot each (compact_runs)
+    chunk_rows: int = 0   # rows a chunk may hold: 0 / chunk, or 112 (chunk = 128: seven row tiles of rows per chunk)
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -114,8 +118,15 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     split: the plan layout -- False / 0: layout 0; True / 1: the TEAM placement (128-slot chunks only), see ``team_placement``;
            3: layout 0 followed by ``compact_runs`` (128-slot chunks only).
     """
+    cap = None            # row tiles a chunk may hold (None: chunk / 16)
+    if chunk == CHUNK_112:
+        if int(split) not in (0, 3):
+            raise ValueError("112-row chunks: layouts 0 and 3 only")
+        if int(split) == 3:
+            return compact_runs(build_plan(gather, scatter, rel, w, n_nodes, num_relations, tile, node_begin, node_end, chunk, False))
+        chunk, cap = 128, 7
     if chunk not in CHUNKS:
-        raise ValueError(f"chunk must be one of {CHUNKS}")
+        raise ValueError(f"chunk must be one of {CHUNKS} (or {CHUNK_112})")
     if split and chunk != 128:
         raise ValueError("the team placement and the run compaction need 128-slot chunks")
     if int(split) == 3:
@@ -168,7 +179,8 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     dstl = key % tile
     gk = key // tile
     gvals, gcnt = torch.unique_consecutive(gk, return_counts=True)
-    gch = (gcnt + (CHUNK - 1)) // CHUNK
+    per = cap if cap is not None else CHUNK // ROWS_PER_MFMA_TILE       # row tiles a chunk holds
+    gch = ((gcnt + 15) // 16 + (per - 1)) // per if cap is not None else (gcnt + (CHUNK - 1)) // CHUNK
     chunk_base = torch.cumsum(gch, 0) - gch
     n_chunks = int(gch.sum())
     n_groups = gvals.shape[0]
@@ -186,9 +198,10 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
     straddle = None
     if not split:
         nt_e = gnt[grp_of_edge]
-        slot = chunk_base[grp_of_edge] * CHUNK + (rank % nt_e) * g16 + rank // nt_e
+        t_e = rank % nt_e                         # the group's row tile: chunk t // per of the group, its row tile t % per
+        slot = (chunk_base[grp_of_edge] + t_e // per) * CHUNK + (t_e % per) * g16 + rank // nt_e
         # slots of the chunk's used row tiles (a multiple of 16; padding sits at the end of every tile)
-        chunk_cnt = (torch.clamp(gnt[grp_of_chunk] - idx_in_grp * (CHUNK // g16), max=CHUNK // g16) * g16).to(torch.int32)
+        chunk_cnt = (torch.clamp(gnt[grp_of_chunk] - idx_in_grp * per, max=per) * g16).to(torch.int32)
     else:
         slot, chunk_cnt, straddle = team_placement(dstl, gcnt, grp_of_edge, rank, chunk_base, grp_of_chunk, idx_in_grp)
     n_slots = n_chunks * CHUNK
@@ -226,7 +239,7 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
                     n_edges=n_edges, tile_ptr=tile_ptr, chunk_rel=chunk_rel, chunk_cnt=chunk_cnt,
                     chunk_tile=chunk_tile, rel_order=rel_order, slot_src=slot_src, slot_w=slot_w,
                     slot_dstl=slot_dstl, slot_row=slot_row, slot_acc=slot_acc, chunk_flags=chunk_flags,
-                    layout=1 if split else 0)
+                    layout=1 if split else 0, chunk_rows=per * g16)
 
 
 def compact_runs(plan: TilePlan) -> TilePlan:
@@ -454,7 +467,8 @@ def padded_width(w: int) -> int:
 # (exact fp32: 10.15 ms where the model says 8.6; bf16 x 3: 8.4 ms where its model -- 1,800 cycles per chunk, 420 per row tile,
 # DESIGN.md 8.0f -- says 9.2)
 _KERNEL_MODEL = {"fp32": (800.0, 650.0, 1.18), "bf16x3": (1800.0, 420.0, 0.91)}
-P3_MAX_TILE = 224          # rgcn_tile3p_kernel: two 48 KiB ring slots + the fp32 accumulator in 160 KiB
+P3_MAX_TILE = 224          # rgcn_tile3p_kernel: two 48 KiB ring slots (any 128-slot chunk) + the fp32 accumulator in 160 KiB
+P3_MAX_TILE_112 = 272      # ... two 42 KiB slots (chunks of at most 112 rows: CHUNK_112)
 
 
 def choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: int, out_channels: int, kernel: str = "fp32",
@@ -508,8 +522,9 @@ def _choose_layout(n_nodes: int, n_edges: int, num_relations: int, in_channels: 
         # the library picks the count the same way (csrc/rgcn_kernels_shared.h tiles_per_workgroup)
         return min(math.ceil(math.ceil(n_tiles / k) / 256) * (k + 0.04) for k in range(1, 17))
 
-    if p3:
-        cands = [(t, 128) for t in range(64, P3_MAX_TILE + 1, 16)] if max(kp, np_) == 64 and min(kp, np_) == 64 else []
+    if p3:      # 128-slot chunks up to tile 224, 112-row chunks (seven row tiles; the kernel's smaller ring slots) up to 272
+        cands = ([(t, 128) for t in range(64, P3_MAX_TILE + 1, 16)] + [(t, CHUNK_112) for t in range(P3_MAX_TILE + 16, P3_MAX_TILE_112 + 1, 16)]
+                 if max(kp, np_) == 64 and min(kp, np_) == 64 else [])
     else:
         cands = [(t, c) for c in CHUNKS for t in range(64, 513, 16)
                  if lds(t, c, 2) <= LDS_BYTES and (c == CHUNK or max(kp, np_) <= 64)]
@@ -590,8 +605,10 @@ def build_graph_plans_torch(edge_index: Tensor, edge_type: Tensor, n_nodes: int,
 def empty_plan(n_nodes: int, node_begin: int, num_relations: int, tile: int, chunk: int, device, layout: int = 0) -> TilePlan:
     """the plan of an empty node range (dist.py: a block wholly past the last node, or squeezed out by a hub's block)"""
     z = lambda dt=torch.int32: torch.zeros(0, dtype=dt, device=device)
+    rows = chunk
+    chunk = 128 if chunk == CHUNK_112 else chunk
     return TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_begin, num_relations=num_relations, tile=tile,
-                    chunk=chunk, n_tiles=0, n_chunks=0, n_edges=0, tile_ptr=torch.zeros(1, dtype=torch.int32, device=device),
+                    chunk_rows=rows, chunk=chunk, n_tiles=0, n_chunks=0, n_edges=0, tile_ptr=torch.zeros(1, dtype=torch.int32, device=device),
                     chunk_rel=z(), chunk_cnt=z(), chunk_tile=z(), chunk_flags=z(), rel_order=z(), slot_src=z(),
                     slot_w=z(torch.float32), slot_dstl=None, slot_row=z(), slot_acc=z(), layout=layout)
 
@@ -605,8 +622,8 @@ def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, t
         raise ValueError("node_begin must be a multiple of the tile size")
     ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, tile, chunk, ws, split)
     plan = TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, tile=tile,
-                    chunk=chunk, n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None,
-                    layout=int(split), **a)
+                    chunk=int(ps.chunk), n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None,
+                    layout=int(split), chunk_rows=int(ps.chunk_rows), **a)
     plan._cstruct = ps
     return plan
 
@@ -626,8 +643,8 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
     edge-parallel direction are the WHOLE graph's, their rows dealt over the ranks (eplan.SharedHeavy, returned in
     ``extras["shared_fwd"]`` / ``["shared_bwd"]``); the pieces' plans hold the light rows and the pseudo rows of their own segments."""
     from . import _lib
-    if chunk not in CHUNKS:
-        raise ValueError(f"chunk must be one of {CHUNKS}")
+    if chunk not in CHUNKS and chunk != CHUNK_112:
+        raise ValueError(f"chunk must be one of {CHUNKS} (or {CHUNK_112})")
     graph, keep = _lib.graph_struct(edge_index, edge_type, n_nodes, num_relations)
     e = int(edge_type.shape[0])
     rs = ranges if ranges is not None else [(fwd_range or (0, n_nodes), bwd_range or (0, n_nodes))]

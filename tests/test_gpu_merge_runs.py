@@ -23,7 +23,8 @@ def _fwd_dx(dev, ei, et, n, r, x, w, root, bias, dg, tile, layout, flags=None):
     of a layout-3 chunk to their heads in LDS"""
     from scaling_rgcn_training_amd import _lib, plan as P
     flags = _lib.FLAG_SPLIT_PRODUCERS if flags is None else flags
-    plans = P.build_graph_plans(ei.to(dev), et.to(dev), n, r, tile, "mean", chunk=128, split=layout)
+    # tiles above 224: chunks of at most 112 rows (seven row tiles) -- the bf16 x 3 kernel's 42 KiB ring slots
+    plans = P.build_graph_plans(ei.to(dev), et.to(dev), n, r, tile, "mean", chunk=112 if tile > 224 and tile <= 272 else 128, split=layout)
     xd, gd = x.to(dev).contiguous(), dg.to(dev).contiguous()
     wd, rd, bd = w.to(dev).contiguous(), root.to(dev).contiguous(), bias.to(dev).contiguous()
     out = torch.full((n, 64), float("nan"), device=dev)
@@ -38,7 +39,8 @@ def _fwd_dx(dev, ei, et, n, r, x, w, root, bias, dg, tile, layout, flags=None):
 @pytest.mark.parametrize("n,e,r,tile,skew,some", [(20000, 60000, 32, 224, False, True), (3000, 30000, 32, 224, False, True),
                                                   (6000, 60000, 32, 224, False, True), (6000, 200000, 32, 224, False, False),
                                                   (4000, 40000, 16, 128, True, None), (300, 2500, 8, 64, False, None),
-                                                  (9000, 90000, 32, 288, False, True)])
+                                                  (9000, 90000, 32, 288, False, True), (9000, 90000, 32, 272, False, True),
+                                                  (6000, 250000, 32, 272, False, None)])
 def test_merged_runs_match_the_oracle_and_layout_0(dev, n, e, r, tile, skew, some, kernel):
     """graphs whose (tile, relation) groups fit one chunk (compacted: runs of 2 and 3, second and third rows in the shadow row
     tiles), groups of several chunks and hub rows (left in layout 0), duplicate triples (unequal weights inside a run: left
@@ -53,8 +55,8 @@ def test_merged_runs_match_the_oracle_and_layout_0(dev, n, e, r, tile, skew, som
     dg = torch.randn(n, 64, generator=g)
     ref, gr = O.rgcn_conv_segments(x.numpy(), ei.numpy(), et.numpy(), w.numpy(), root.numpy(), bias.numpy(), dg.numpy())
     kf = None if kernel == "bf16x3" else 0
-    if kernel == "bf16x3" and tile > 224:
-        pytest.skip("the bf16 x 3 kernel's ring leaves room for tiles up to 224")
+    if kernel == "bf16x3" and tile > 272:
+        pytest.skip("the bf16 x 3 kernel's ring leaves room for tiles up to 272 (chunks of at most 112 rows)")
     out3, dx3, p3 = _fwd_dx(dev, ei, et, n, r, x, w, root, bias, dg, tile, 3, kf)
     out0, dx0, p0 = _fwd_dx(dev, ei, et, n, r, x, w, root, bias, dg, tile, 0, kf)
     assert p3.fwd.layout == 3 and p3.bwd.layout == 3

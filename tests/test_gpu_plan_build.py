@@ -20,13 +20,16 @@ def _compare(ei, et, n, r, tile, chunk, aggr="mean", fr=None, br=None, split=Fal
     if chunk == 128 and not split:          # every 128-slot case also in the split placement (plan layout 1) and with the
         _compare(ei, et, n, r, tile, chunk, aggr, fr, br, split=True)       # (destination, relation) runs compacted (layout 3)
         _compare(ei, et, n, r, tile, chunk, aggr, fr, br, split=3)
+        # ... and with chunks that hold at most 112 rows (seven row tiles; rgcn_tile3p_kernel's smaller ring slots), layouts 0 and 3
+        _compare(ei, et, n, r, tile, 112, aggr, fr, br, split=0)
+        _compare(ei, et, n, r, tile, 112, aggr, fr, br, split=3)
     dev_plans = P.build_graph_plans_device(ei, et, n, r, tile, aggr, fr, br, chunk, split=split)
     ref_plans = P.build_graph_plans_torch(ei, et, n, r, tile, aggr, fr, br, chunk, split=split)
     torch.cuda.synchronize()
     for name in ("fwd", "bwd"):
         a, b = getattr(dev_plans, name), getattr(ref_plans, name)
         for f in ("n_nodes", "node_begin", "node_end", "num_relations", "tile", "chunk", "n_tiles", "n_chunks", "n_edges", "n_units",
-                  "layout"):
+                  "layout", "chunk_rows"):
             assert getattr(a, f) == getattr(b, f), (name, f, getattr(a, f), getattr(b, f))
         for f in ARRAYS:
             x, y = getattr(a, f), getattr(b, f)

@@ -321,8 +321,10 @@ def test_compact_runs_keeps_the_layer_and_its_own_invariants(n, e, r, tile):
     ew = P.edge_weights(ei[0], ei[1], et, r, "mean")
     some = 0
     for gather, scatter in ((ei[0], ei[1]), (ei[1], ei[0])):
-        p0 = P.build_plan(gather, scatter, et, ew, n, r, tile, chunk=128)
-        p3 = P.build_plan(gather, scatter, et, ew, n, r, tile, chunk=128, split=3)
+        ch = 112 if tile > 224 else 128          # tiles above 224: chunks of at most seven row tiles of rows
+        p0 = P.build_plan(gather, scatter, et, ew, n, r, tile, chunk=ch)
+        p3 = P.build_plan(gather, scatter, et, ew, n, r, tile, chunk=ch, split=3)
+        assert p0.chunk == 128 and p0.chunk_rows == ch and int(p0.chunk_cnt.max()) <= ch
         assert p3.layout == 3 and p3.n_chunks == p0.n_chunks
         np.testing.assert_allclose(emulate_spmm(p3, x, w_all, bias.numpy()), emulate_spmm(p0, x, w_all, bias.numpy()), rtol=0, atol=1e-12)
         fl = p3.chunk_flags.numpy().astype(np.int64)
