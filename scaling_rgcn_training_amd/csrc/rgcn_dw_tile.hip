@@ -429,7 +429,8 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     // the fold period of THIS wave: kDwFlushUnits where the wave has a long walk (the headline: ~1,000 units per wave), an eighth
     // of its walk (at least 16 units) where it is shorter -- there the folds cost nothing that matters and a chain of ~1K rows
     // instead of ~7K keeps the sums as accurate as ATen's blocked ones (tests/test_gpu_parity.py holds 2 x the CPU loop's error)
-    const int fold_period = kDwFlushUnits > 0 ? min(kDwFlushUnits, max(16, nun >> 3)) : 0;
+    // (the exact-fp32 form has no bias to cancel, only chains to keep short: four times the period)
+    const int fold_period = kDwFlushUnits > 0 ? min(SPLIT ? kDwFlushUnits : 4 * kDwFlushUnits, max(16, nun >> 3)) : 0;
     int fold_left = fold_period;
     dma_tile(t0, 0);
     int k = 0;

@@ -302,8 +302,14 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
         // retire these loads in the compiler's scoreboard HERE: otherwise it keeps "maybe pending" waits
         // in front of the loop's MFMAs, and those s_waitcnt vmcnt(N) would also wait for the asm prefetch
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        int cnt_pre = ldc(a.chunk_cnt, c0);
-        int flags_pre = ldc(a.chunk_flags, c0);
+        // per-chunk words one iteration ahead through scalar BUFFER loads with one running offset (rgcn_common.h sbuf_load;
+        // round 4, as in rgcn_tile3p_kernel): chunk it + 1's slot count and flags, chunk it + 3's relation
+        const i32x4 rs_cnt = make_srsrc(a.chunk_cnt + c0 + 1, 4L * (a.n_chunks - c0 - 1));
+        const i32x4 rs_flg = make_srsrc(a.chunk_flags + c0 + 1, 4L * (a.n_chunks - c0 - 1));
+        const i32x4 rs_rel = make_srsrc(a.chunk_rel + c0 + 3, 4L * (a.n_chunks - c0 - 3));
+        unsigned moff = 0;
+        int ld_cnt = ldc(a.chunk_cnt, c0);
+        int ld_flg = ldc(a.chunk_flags, c0);
         // Relation ids one and two chunks ahead.  The NEXT relation's weight fragments are prefetched into `bnext` at the
         // END of an iteration, just before the barrier: by then the producers have issued (and waited for) all their
         // LDS-DMAs, so the CU's vector-memory queue is empty and these few loads issue at once.  Issued at the TOP of
@@ -312,7 +318,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
         // that does not scale with the chunk" of the stamp profile; tools/debug/stamps.py).
         constexpr bool kAsmPrefetch = SL * KT <= 4;
         int rel_n1 = nch > 1 ? ldc(a.chunk_rel, c0 + 1) : rel_cur;
-        int rel_n2 = nch > 2 ? ldc(a.chunk_rel, c0 + 2) : rel_n1;
+        int ld_rel = nch > 2 ? ldc(a.chunk_rel, c0 + 2) : rel_n1;
         auto prefetch_rel = [&](int rel) {
 #pragma unroll
             for (int s = 0; s < SL; ++s) {
@@ -342,16 +348,16 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             const int chunk = c0 + it;
             const int buf = it % NBUF;
             // chunk metadata arrives one iteration ahead (scalar loads issued a whole chunk earlier)
-            const int cnt = cnt_pre;
-            const int flags_chunk = flags_pre;
+            const int cnt = ld_cnt;                   // (fetched an iteration ago, waited for behind that iteration's barrier)
+            const int flags_chunk = ld_flg;
             const int rel_next = rel_n1;
-            const int rel_next2 = rel_n2;
-            if (it + 1 < nch) {
-                cnt_pre = ldc(a.chunk_cnt, chunk + 1);
-                flags_pre = ldc(a.chunk_flags, chunk + 1);
-            }
-            rel_n1 = rel_n2;
-            if (it + 3 < nch) rel_n2 = ldc(a.chunk_rel, chunk + 3);
+            const int rel_next2 = ld_rel;
+            rel_n1 = ld_rel;
+            sbuf_load(ld_cnt, rs_cnt, moff);
+            sbuf_load(ld_flg, rs_flg, moff);
+            sbuf_load(ld_rel, rs_rel, moff);
+            moff += 4;
+            (void)chunk;
 #ifdef RGCN_STAMPS
             asm volatile("" ::"s"(cnt), "s"(rel_next));
 #endif
@@ -651,6 +657,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
             }
             STAMP(t3);
             wg_barrier();
+            sbuf_wait(ld_cnt, ld_flg, ld_rel);      // the next chunk's words: retired by wg_barrier's lgkmcnt(0); uses stay behind here
             STAMP(t4);
             if (it + 1 == tend && it + 1 < nch) {
                 // this chunk closed a tile: store it and reset the accumulator (the 256 consumer threads; the producers
