@@ -79,7 +79,7 @@ def heavy_edge_masks(edge_index: Tensor, edge_type: Tensor, n_nodes: int):
 
 def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge_index: Optional[Tensor] = None,
                  balance: Optional[bool] = None, exchange: str = "full", emulate=None, edge_type: Optional[Tensor] = None,
-                 split_hubs: bool = True) -> Optional[DistContext]:
+                 split_hubs: bool = True, paths=("ep", "ep")) -> Optional[DistContext]:
     """edge_index given: keep the uniform cut (one in-place all-gather per piece) while its blocks' edge counts stay within
     BALANCE_TOLERANCE of their mean, else cut by edge count (``balance`` True / False pins the choice).
     ``exchange``: "full" | "needed" (conv.DistContext).  ``emulate = (world, rank)``: no process group -- the context of rank
@@ -102,9 +102,11 @@ def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge
         ei_cost, shared_rows = edge_index, 0.0
         if split_hubs and edge_type is not None and edge_index.shape[1] > 0:
             # rows of heavy segments are dealt over all ranks (eplan.SharedHeavy) wherever a direction takes the edge-parallel
-            # path: they are not a block's cost.  (The tile kernels would walk them in their block; the cut assumes the path a
-            # hub graph takes.)  What stays in a block: its light rows and one pseudo row per heavy segment (negligible).
+            # path (``paths``: what the layer will run per direction; a direction on the tile kernels walks its hubs in their
+            # block): they are not a block's cost.  What stays in a block: its light rows and one pseudo row per heavy segment.
             hf, hb = heavy_edge_masks(edge_index, edge_type, n_nodes)
+            hf = hf if paths[0] == "ep" else None
+            hb = hb if paths[1] == "ep" else None
             if hf is not None or hb is not None:
                 zero = torch.zeros(edge_index.shape[1], dtype=torch.bool, device=edge_index.device)
                 hf = zero if hf is None else hf
@@ -293,5 +295,14 @@ def attach(module: torch.nn.Module, n_nodes: int, n_edges: int, group=None, edge
     edge-parallel path deals over all ranks (eplan.SharedHeavy)."""
     for m in module.modules():
         if isinstance(m, RGCNConv):
-            tile = m.layout(n_nodes, n_edges)[0]
-            m.dist = make_context(n_nodes, tile, group, pieces, edge_index, balance, exchange, emulate, edge_type, split_hubs)
+            tile, chunk = m.layout(n_nodes, n_edges)
+            paths = ("ring", "ring")
+            if edge_type is not None and split_hubs and edge_index is not None:
+                # the path every rank will take per direction (the whole graph's choice: cached_rank_plans decides the same way)
+                paths = m.path
+                if paths == "auto":
+                    from .eplan import decide_paths
+                    paths = decide_paths(edge_index, n_nodes, m.num_relations, m.in_channels, m.out_channels, tile, chunk)
+                elif isinstance(paths, str):
+                    paths = (paths, paths)
+            m.dist = make_context(n_nodes, tile, group, pieces, edge_index, balance, exchange, emulate, edge_type, split_hubs, tuple(paths))
