@@ -19,7 +19,7 @@ PLAN_ARRAYS = ("tile_ptr", "chunk_rel", "chunk_cnt", "chunk_tile", "chunk_flags"
 
 class rgcn_plan(C.Structure):           # struct rgcn_plan, include/rgcn_mi355x.h
     _fields_ = [(k, i32) for k in ("n_nodes", "n_owned", "num_relations", "tile", "n_tiles", "n_chunks", "chunk", "n_units",
-                                   "layout", "chunk_rows")] + [(k, vp) for k in PLAN_ARRAYS]
+                                   "layout", "chunk_rows")] + [(k, vp) for k in PLAN_ARRAYS] + [("slot_src2", vp)]      # (layout 5 only: NULL here)
 
 
 class rgcn_graph(C.Structure):          # struct rgcn_graph: the COO tensors of graphs/graph.py:55-69, as they are

@@ -95,7 +95,11 @@ typedef struct rgcn_plan {
                             * second / third rows, bit 19 "the rows of a run differ in
                             * weight" (a shadow slot's slot_acc then holds the float weight / head's weight).  Walked by rgcn_fwd / rgcn_bwd_dx with RGCN_FLAG_SPLIT_PRODUCERS on 64 x 64 layers only (the
                             * producer waves add a run's rows before they cut them: aggregate, then transform); every other
-                            * entry point answers RGCN_ERR_PLAN */
+                            * entry point answers RGCN_ERR_PLAN;
+                            * 5 (chunk = 64; the plan rgcn_bwd_dw_tiles walks): layout 0 with PAIRS of rows of one (destination, relation,
+                            * weight) on one slot in the (tile, relation) groups of at most two chunks, see slot_src2; n_units / rel_order
+                            * hold the units that are left (its rgcn_plan_build_finish synchronises the stream to count them);
+                            * rgcn_bwd_dw answers RGCN_ERR_PLAN */
     int32_t chunk_rows;    /* rows a chunk may hold: = chunk, or 112 (chunk = 128: seven row tiles of rows, the eighth free for shadow
                             * rows; built by rgcn_plan_build_begin(chunk = 112)): what rgcn_tile3p_kernel's 42 KiB ring slots hold,
                             * which leaves its accumulator room for tiles up to 272.  0 is read as `chunk` */
@@ -116,6 +120,9 @@ typedef struct rgcn_plan {
                                 * MFMA row tile of the slot ending this slot's run of equal destinations) << 24 |
                                 * (accumulator row written); the row is the slot's row in the tile if the slot
                                 * ends its run, else `tile` (dummy row) */
+    const int32_t* slot_src2;  /* layout 5 only (else NULL): [n_chunks * 8] the SECOND gathered row of the slots 0..3 and 32..35 of
+                                * every 64-slot unit (padding = n_nodes): rgcn_bwd_dw_tiles adds it to the slot's first row before
+                                * the contraction -- two rows with one (destination, relation) and one weight on ONE slot */
 } rgcn_plan_t;
 
 int rgcn_abi_version(void);

@@ -40,7 +40,7 @@ class RgcnPlanStruct(C.Structure):
         ("layout", C.c_int32), ("chunk_rows", C.c_int32),
         ("tile_ptr", C.c_void_p), ("chunk_rel", C.c_void_p), ("chunk_cnt", C.c_void_p),
         ("chunk_tile", C.c_void_p), ("chunk_flags", C.c_void_p), ("rel_order", C.c_void_p), ("slot_src", C.c_void_p),
-        ("slot_w", C.c_void_p), ("slot_row", C.c_void_p), ("slot_acc", C.c_void_p),
+        ("slot_w", C.c_void_p), ("slot_row", C.c_void_p), ("slot_acc", C.c_void_p), ("slot_src2", C.c_void_p),
     ]
 
 
@@ -171,7 +171,8 @@ def plan_struct(plan) -> RgcnPlanStruct:
         int(getattr(plan, "layout", 0)), int(getattr(plan, "chunk_rows", 0) or plan.chunk),
         plan.tile_ptr.data_ptr(), plan.chunk_rel.data_ptr(), plan.chunk_cnt.data_ptr(),
         plan.chunk_tile.data_ptr(), plan.chunk_flags.data_ptr(), plan.rel_order.data_ptr(), plan.slot_src.data_ptr(),
-        plan.slot_w.data_ptr(), plan.slot_row.data_ptr(), plan.slot_acc.data_ptr())
+        plan.slot_w.data_ptr(), plan.slot_row.data_ptr(), plan.slot_acc.data_ptr(),
+        _ptr(getattr(plan, "slot_src2", None)))
     return plan._cstruct
 
 
@@ -335,6 +336,8 @@ def plan_build(graph: RgcnGraphStruct, w: torch.Tensor, transposed: bool, node_b
             "slot_src": torch.empty(sizes.n_slots, **i32), "slot_w": torch.empty(sizes.n_slots, dtype=torch.float32, device=dev),
             "slot_row": torch.empty(sizes.n_slots, **i32), "slot_acc": torch.empty(sizes.n_slots, **i32),
         }
+        if int(split) == 5:      # second rows of the pairs (the tile-major weight-gradient plan)
+            arr["slot_src2"] = torch.empty(max(sizes.n_chunks * 8, 1), **i32)
         ps = RgcnPlanStruct()
         for k, t in arr.items():
             setattr(ps, k, t.data_ptr())

@@ -869,6 +869,7 @@ extern "C" int rgcn_bwd_dw(const rgcn_plan_t* plan, const float* x, int ldx, int
     int st = check_plan(plan);
     if (st != RGCN_OK) return st;
     if (plan->layout == 3) return RGCN_ERR_PLAN;       // (shadow slots: only the forward / dX kernel knows them)
+    if (plan->layout == 5) return RGCN_ERR_PLAN;       // (second rows of pairs: only the tile-major kernel adds them)
     if (!x || !g || !workspace) return RGCN_ERR_NULL;
     if ((st = check_stride(ldx, din)) != RGCN_OK) return st;
     if ((st = check_stride(ldg, dout)) != RGCN_OK) return st;

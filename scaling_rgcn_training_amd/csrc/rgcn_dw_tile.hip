@@ -101,6 +101,8 @@ struct DwTileArgs {
     const int* slot_src;
     const float* slot_w;
     const int* slot_row;
+    const int* slot_src2;   // PAIRS: [units][8] second rows of the unit's pair heads (slots 32 h + kq, h = 0 / 1: the first four slots
+                            // of either half), padding = n_nodes; NULL otherwise
     const int* walk_ptr;    // [num_rel][walkers + 1]: rel_order positions where walker p's tiles of relation r begin
     const float* x;
     const float* g;
@@ -115,7 +117,11 @@ struct DwTileArgs {
 // 32-row k-steps of that MFMA = the two halves of the register pipeline, with slot 32 h + 4 s + kq as k index 8 kq + s on both
 // operands (a sum over k does not care which slot sits where, only that A and B agree).  96 MFMAs of 16 cycles per half
 // against 256 of 32: the exact-fp32 form of this kernel is bound by the fp32 MFMA rate.
-template <bool SPLIT>
+// PAIRS (round 4, plan layout 5: rgcn_plan.hip dw_pairs_kernel): the two rows of a (destination, relation) pair take ONE k-slot --
+// x[src] + x[src2] is formed in registers before the cut (mean aggregation gives both rows the same weight, and both meet the same
+// gradient row): the head of a pair sits on one of the first four slots of a half (register 0 of the half's pipeline), its second
+// row arrives by ONE more row load per half with the same lane geometry (padding where a slot has no second row: zeros, no traffic).
+template <bool SPLIT, bool PAIRS = false>
 __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a) {
     constexpr int T = kDwTileT, NP = 64, HS = 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][T][64]
@@ -163,13 +169,20 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     struct Idx {      // lane l: slot l of the unit
         int h, g;
         float w;
+        int h2;       // PAIRS: lanes 0..7: second rows of slots 0..3 (lanes 0..3) and 32..35 (lanes 4..7)
     };
     auto unit_of = [&](int k) { return ldc(a.rel_order, i0 + (k < nun ? k : (nun > 0 ? nun - 1 : 0))); };
     auto load_idx = [&](int unit) {
         const size_t base = (size_t)unit * kChunk + lane;
-        return Idx{a.slot_src[base], a.slot_row[base], a.slot_w[base]};
+        int h2 = 0;
+        if constexpr (PAIRS) h2 = a.slot_src2[(size_t)unit * 8 + (lane & 7)];
+        return Idx{a.slot_src[base], a.slot_row[base], a.slot_w[base], h2};
     };
-    auto issue_half = [&](f32x4 (&a4)[HS], const Idx& ix, int h) {
+    auto issue_half = [&](f32x4 (&a4)[HS], f32x4& pair, const Idx& ix, int h) {
+        if constexpr (PAIRS) {      // the second rows of slots 32 h + kq: lane 4 h + kq of the index vector
+            const int i2 = __builtin_amdgcn_ds_bpermute(perm + 16 * h, ix.h2);
+            pair = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24((unsigned)i2, rbx) + colb), 0, 0));
+        }
         int ih[HS];
 #pragma unroll
         for (int s = 0; s < HS; ++s) ih[s] = __builtin_amdgcn_ds_bpermute(perm + 16 * (HS * h + s), ix.h);
@@ -182,7 +195,8 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
     };
     // half a unit: 8 k-steps of 4 rows; gradient rows from the LDS tile (row ids local to the tile, padding clamped: its
     // weight is 0 and every LDS word is a finite number)
-    auto compute_half = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, int nks, const float* gbuf, int tile_row0) {
+    auto compute_half = [&](f32x4 (&a4)[HS], const f32x4& pair, const Idx& ix, int h, int ngrp, int nks, const float* gbuf, int tile_row0) {
+        if constexpr (PAIRS) a4[0] += pair;
         const unsigned loc = (unsigned)(ix.g - tile_row0);
         const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));    // byte offset of this lane's slot row
         float wv[HS];
@@ -235,8 +249,9 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
         split3_pair(v0, v1, h, m, l);
     };
     // half a unit as ONE 32-row k-step (a half with no valid slot is skipped; padding slots inside one have weight 0)
-    auto compute_half3 = [&](const f32x4 (&a4)[HS], const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {
+    auto compute_half3 = [&](f32x4 (&a4)[HS], const f32x4& pair, const Idx& ix, int h, int ngrp, const float* gbuf, int tile_row0) {
         if (2 * h >= ngrp) return;      // (ix.w carries the period's sign, see fold_into_slab)
+        if constexpr (PAIRS) a4[0] += pair;
         const unsigned loc = (unsigned)(ix.g - tile_row0);
         const int goff = (int)((loc < (unsigned)T ? loc : (unsigned)(T - 1)) * (unsigned)(NP * 4));
         float wv[HS];
@@ -448,8 +463,9 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
 #endif
     Idx ix_cur = load_idx(uid_cur), ix_nxt = load_idx(uid_nxt);
     f32x4 s0[HS], s1[HS];
-    if (nun > 0) issue_half(s0, ix_cur, 0);
-    constexpr int kInFlight = RGCN_DW_VECTOR_WALK ? 14 : 11;      // 8 row loads + 3 index loads (+ 3 walk words)
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+    if (nun > 0) issue_half(s0, p0, ix_cur, 0);
+    constexpr int kInFlight = (RGCN_DW_VECTOR_WALK ? 14 : 11) + (PAIRS ? 2 : 0);      // 8 (+ 1) row loads + 3 (+ 1) index loads (+ 3 walk words)
     bool walked = nun > 0;      // at least kInFlight vector-memory operations were issued after the pending tile's DMAs
     for (int t = t0; t < t1; ++t) {
         // The DMAs of tile t were issued a tile ago (or in the prologue).  If the wave has walked a unit since (or issued the
@@ -473,21 +489,21 @@ __global__ void __launch_bounds__(512, 2) rgcn_dw_tile_kernel(const DwTileArgs a
             const int ngrp = (cnt_cur + 15) >> 4, nks = (cnt_cur + 3) >> 2;
             walked = true;
             DWS(0)               // (loop overhead, walk words)
-            issue_half(s1, ix_cur, 1);
+            issue_half(s1, p1, ix_cur, 1);
             pin_loads();
             __builtin_amdgcn_sched_barrier(0);
             DWS(1)               // second half's rows issued
             if constexpr (SPLIT && kDwFlushUnits > 0 && RGCN_DW_FLUSH_SIGNS) ix_cur.w *= sgn;
-            if constexpr (SPLIT) compute_half3(s0, ix_cur, 0, ngrp, gbuf, t * T);
-            else compute_half(s0, ix_cur, 0, ngrp, nks, gbuf, t * T);
+            if constexpr (SPLIT) compute_half3(s0, p0, ix_cur, 0, ngrp, gbuf, t * T);
+            else compute_half(s0, p0, ix_cur, 0, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             const Idx ix_nn = load_idx(uid_nn);
-            issue_half(s0, ix_nxt, 0);
+            issue_half(s0, p0, ix_nxt, 0);
             pin_loads();
             __builtin_amdgcn_sched_barrier(0);
             DWS(6)               // next unit's indices and first-half rows issued
-            if constexpr (SPLIT) compute_half3(s1, ix_cur, 1, ngrp, gbuf, t * T);
-            else compute_half(s1, ix_cur, 1, ngrp, nks, gbuf, t * T);
+            if constexpr (SPLIT) compute_half3(s1, p1, ix_cur, 1, ngrp, gbuf, t * T);
+            else compute_half(s1, p1, ix_cur, 1, ngrp, nks, gbuf, t * T);
             __builtin_amdgcn_sched_barrier(0);
             ++k;
             if constexpr (kDwFlushUnits > 0) {
@@ -593,7 +609,7 @@ extern "C" int rgcn_dw_tiles_walk(const rgcn_plan_t* plan, int32_t* walk_ptr, vo
     if ((st = check_device()) != RGCN_OK) return st;
     if ((st = check_plan(plan)) != RGCN_OK) return st;
     if (walk_ptr == nullptr) return RGCN_ERR_NULL;
-    if (plan->tile != kDwTileT || plan->chunk != 64 || plan->layout != 0 || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
+    if (plan->tile != kDwTileT || plan->chunk != 64 || (plan->layout != 0 && plan->layout != 5) || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
     const int n = plan->num_relations * (kDwTileWalkers + 1);
     hipLaunchKernelGGL(rgcn_dw_walk_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan->rel_order,
                        plan->chunk_rel, plan->chunk_tile, plan->n_units, plan->n_tiles, plan->num_relations, kDwTileWalkers, walk_ptr);
@@ -613,7 +629,7 @@ extern "C" int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_pt
     if ((st = check_stride(ldx, din)) != RGCN_OK) return st;
     if ((st = check_stride(ldg, dout)) != RGCN_OK) return st;
     if (padded_width(din) != 64 || padded_width(dout) != 64) return RGCN_ERR_WIDTH;
-    if (plan->tile != kDwTileT || plan->chunk != 64 || plan->layout != 0 || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
+    if (plan->tile != kDwTileT || plan->chunk != 64 || (plan->layout != 0 && plan->layout != 5) || plan->num_relations > kDwTileMaxRel) return RGCN_ERR_PLAN;
     if (workspace_bytes < rgcn_bwd_dw_tiles_workspace_bytes(plan->num_relations)) return RGCN_ERR_WORKSPACE;
     if ((st = check_device()) != RGCN_OK) return st;
     DwTileArgs a;
@@ -640,12 +656,19 @@ extern "C" int rgcn_bwd_dw_tiles(const rgcn_plan_t* plan, const int32_t* walk_pt
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float) * 2 * kDwTileT * 64;
     const bool split = (flags & RGCN_FLAG_SPLIT_PRODUCERS) != 0;
+    a.slot_src2 = plan->layout == 5 ? plan->slot_src2 : nullptr;
+    if (plan->layout == 5 && a.slot_src2 == nullptr) return RGCN_ERR_NULL;
     hipError_t e = split ? allow_full_lds<rgcn_dw_tile_kernel<true>>() : allow_full_lds<rgcn_dw_tile_kernel<false>>();
     if (e != hipSuccess) return (int)e;
     // walkers without tiles leave their slabs untouched: clear what the reduction reads
     e = hipMemsetAsync(workspace, 0, rgcn_bwd_dw_tiles_workspace_bytes(plan->num_relations), s);
     if (e != hipSuccess) return (int)e;
-    if (split) hipLaunchKernelGGL(rgcn_dw_tile_kernel<true>, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+    if (a.slot_src2 != nullptr) {      // plan layout 5: pairs of rows on one k-slot
+        e = split ? allow_full_lds<rgcn_dw_tile_kernel<true, true>>() : allow_full_lds<rgcn_dw_tile_kernel<false, true>>();
+        if (e != hipSuccess) return (int)e;
+        if (split) hipLaunchKernelGGL((rgcn_dw_tile_kernel<true, true>), dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((rgcn_dw_tile_kernel<false, true>), dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
+    } else if (split) hipLaunchKernelGGL(rgcn_dw_tile_kernel<true>, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
     else hipLaunchKernelGGL(rgcn_dw_tile_kernel<false>, dim3(4 * kDwTileWalkers), dim3(512), lds, s, a);
     if ((st = (int)hipGetLastError()) != 0) return st;
     hipLaunchKernelGGL(rgcn_dw_tile_reduce_kernel, dim3(plan->num_relations, (din * dout + 255) / 256), dim3(256), 0, s, a.slabs,

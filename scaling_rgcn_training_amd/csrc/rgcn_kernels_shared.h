@@ -235,7 +235,8 @@ static int tiles_per_workgroup(int n_tiles) {
 }
 
 // (layout 2 -- the edge-parallel path's dense relation-major units handed to rgcn_bwd_dw -- has no tiles to walk: a heavy part
-// of a few units on a graph of several 32768-node pseudo tiles is a valid plan, so the chunks-per-tile bound does not apply to it)
+// of a few units on a graph of several 32768-node pseudo tiles is a valid plan, so the chunks-per-tile bound does not apply to it;
+// layout 5 -- pairs of rows on one slot -- leaves chunks EMPTY: fewer units than chunks)
 static int check_plan(const rgcn_plan_t* p) {
     if (p == nullptr) return RGCN_ERR_NULL;
     if (!p->tile_ptr || !p->chunk_rel || !p->chunk_cnt || !p->chunk_tile || !p->chunk_flags || !p->rel_order ||
@@ -244,7 +245,7 @@ static int check_plan(const rgcn_plan_t* p) {
         return RGCN_ERR_NULL;
     if (p->n_nodes <= 0 || p->n_owned <= 0 || p->num_relations <= 0 || p->tile <= 0 || (p->tile % 16) != 0 || p->tile > 32768 ||
         p->n_tiles <= 0 || (p->layout != 2 && p->n_chunks < p->n_tiles) || p->n_chunks <= 0 || (long)p->n_tiles * p->tile < p->n_owned ||
-        (p->chunk != 64 && p->chunk != 128) || p->n_units < p->n_chunks || p->n_units > p->n_chunks * (p->chunk / 64))
+        (p->chunk != 64 && p->chunk != 128) || (p->layout != 5 && p->n_units < p->n_chunks) || p->n_units > p->n_chunks * (p->chunk / 64))
         return RGCN_ERR_PLAN;
     return RGCN_OK;
 }

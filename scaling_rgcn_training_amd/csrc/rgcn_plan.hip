@@ -597,6 +597,136 @@ __global__ void __launch_bounds__(kCompactThreads) compact_runs_kernel(u32 n_chu
     chunk_flags[c] = (int32_t)((ns1 << 16) | (ns2 << 18) | (uneq << 19) | (nh << 20));
 }
 
+// Layout 5 = layout 0 (64-slot chunks: the tile-major weight-gradient kernel's units) + this pass (plan.dw_pairs is its twin): the
+// weight gradient of a relation is a sum over slots of (w x[src])^T g[row], so two rows with ONE (destination, relation) and ONE
+// weight -- a pair -- take ONE slot if x[src] + x[src2] is formed first.  Group-local, and only where it is simple: (tile, relation)
+// groups of one or two chunks (128 rows: all but hubs).  The group's rows in sorted order are cut into runs of equal (row, weight),
+// every run into pairs (+ one single row if its length is odd); heads = pairs + singles are dealt back over the group's chunks,
+// 64 per unit, densely from slot 0.  The kernel's lane geometry wants the head of a pair on one of the first four slots of a
+// 32-slot half (register 0 of the half's row pipeline): a unit of n heads has 4 such places if n <= 32, else 8; pairs beyond the
+// group's places stay two single rows.  slot_src2[unit][8]: the second rows of slots 0..3 and 32..35 (padding: n_nodes).  Chunks
+// the group no longer needs get chunk_cnt 0 and drop out of rel_order (the unit list is built after this pass).
+constexpr int kPairThreads = 32;
+__global__ void __launch_bounds__(kPairThreads) dw_pairs_kernel(u32 n_chunks, u32 n_nodes, u32 n_own, const int32_t* __restrict__ chunk_rel,
+                                const int32_t* __restrict__ chunk_tile, int32_t* __restrict__ chunk_cnt, int32_t* __restrict__ slot_src,
+                                float* __restrict__ slot_w, int32_t* __restrict__ slot_row, int32_t* __restrict__ slot_src2) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int32_t rel = chunk_rel[c], t = chunk_tile[c];
+    if (c > 0 && chunk_rel[c - 1] == rel && chunk_tile[c - 1] == t) return;      // not the group's first chunk
+    u32 m = 1;
+    while (c + m < n_chunks && chunk_rel[c + m] == rel && chunk_tile[c + m] == t) ++m;
+    if (m > 2) return;                                                           // a hub's group: left as it is
+    u32 nt = 0;
+    for (u32 i = 0; i < m; ++i) nt += (u32)chunk_cnt[c + i] / 16u;
+    if (nt == 0) return;
+    __shared__ int32_t s_src[kPairThreads][129], s_row[kPairThreads][129];
+    __shared__ u32 s_w[kPairThreads][129];
+    int32_t* lsrc = s_src[threadIdx.x];
+    int32_t* lrow = s_row[threadIdx.x];
+    u32* lw = s_w[threadIdx.x];
+    const size_t base = (size_t)c * 64u;
+    u32 n = 0;
+    for (u32 j = 0; j < nt * 16u; ++j) {      // the group's rows in sorted order: row j sits on row tile j mod nt at place j div nt
+        const u32 tt = j % nt;
+        const size_t sl = base + (size_t)(tt / 4u) * 64u + (size_t)(tt % 4u) * 16u + j / nt;
+        const int32_t sv = slot_src[sl];
+        if ((u32)sv == n_nodes) break;
+        lsrc[n] = sv;
+        lrow[n] = slot_row[sl];
+        lw[n] = __float_as_uint(slot_w[sl]);
+        ++n;
+    }
+    // pairs inside runs of equal (row, weight)
+    u32 P = 0;
+    for (u32 j = 0; j < n;) {
+        u32 len = 1;
+        while (j + len < n && lrow[j + len] == lrow[j] && lw[j + len] == lw[j]) ++len;
+        P += len / 2u;
+        j += len;
+    }
+    if (P == 0) return;
+    // how many pairs the units have places for: demote pairs (two single heads each) until they fit.  H heads fill
+    // U = ceil(H / 64) units densely from slot 0, 64 per unit; a unit of nu heads has min(4, nu) pair places on slots 0..3 and,
+    // past 32 heads, min(4, nu - 32) more on slots 32..35
+    u32 H = n - P;
+    auto unit_heads = [&](u32 u) { return H - 64u * u < 64u ? H - 64u * u : 64u; };
+    auto places = [&](u32 u) {
+        const u32 nu = unit_heads(u);
+        return (nu < 4u ? nu : 4u) + (nu > 32u ? (nu - 32u < 4u ? nu - 32u : 4u) : 0u);
+    };
+    for (;;) {
+        const u32 U = (H + 63u) / 64u;
+        u32 cap = 0;
+        for (u32 u = 0; u < U; ++u) cap += places(u);
+        if (P <= cap) break;
+        --P;
+        ++H;
+    }
+    const u32 U = (H + 63u) / 64u;          // <= 2: the group had at most 128 rows
+    u32 pairs_in[2] = {0u, 0u};
+    {
+        u32 left = P;
+        for (u32 u = 0; u < U; ++u) {
+            pairs_in[u] = left < places(u) ? left : places(u);
+            left -= pairs_in[u];
+        }
+    }
+    // clear the group's chunks, then deal the heads in sorted order: the first P pairs met become pair heads on the pair places
+    // (unit 0's first), every other row a single head on the next slot that is not a taken pair place
+    for (u32 i = 0; i < m * 64u; ++i) {
+        slot_src[base + i] = (int32_t)n_nodes;
+        slot_w[base + i] = 0.f;
+        slot_row[base + i] = (int32_t)n_own;
+    }
+    auto is_pair_place = [&](u32 u, u32 sl) {
+        if (sl < 4u) return sl < pairs_in[u];
+        if (sl >= 32u && sl < 36u) return sl - 28u < pairs_in[u];
+        return false;
+    };
+    u32 pair_left = P, next_pair[2] = {0u, 0u}, next_single[2] = {0u, 0u}, single_u = 0;
+    for (u32 j = 0; j < n;) {
+        u32 len = 1;
+        while (j + len < n && lrow[j + len] == lrow[j] && lw[j + len] == lw[j]) ++len;
+        u32 k = 0;
+        while (k < len) {
+            const bool as_pair = k + 1 < len && pair_left > 0;
+            u32 u, sl;
+            if (as_pair) {
+                u = next_pair[0] < pairs_in[0] ? 0u : 1u;
+                const u32 kk = next_pair[u]++;
+                sl = kk < 4u ? kk : 28u + kk;                  // 0..3, then 32..35
+                --pair_left;
+            } else {
+                u = single_u;
+                for (;;) {
+                    while (next_single[u] < unit_heads(u) && is_pair_place(u, next_single[u])) ++next_single[u];
+                    if (next_single[u] < unit_heads(u)) break;
+                    single_u = ++u;
+                }
+                sl = next_single[u]++;
+            }
+            const size_t g = base + (size_t)u * 64u + sl;
+            slot_src[g] = lsrc[j + k];
+            slot_w[g] = __uint_as_float(lw[j + k]);
+            slot_row[g] = lrow[j + k];
+            if (as_pair) {
+                slot_src2[(size_t)(c + u) * 8u + (sl < 4u ? sl : sl - 28u)] = lsrc[j + k + 1];
+                k += 2;
+            } else {
+                k += 1;
+            }
+        }
+        j += len;
+    }
+    for (u32 i = 0; i < m; ++i) chunk_cnt[c + i] = i < U ? (int32_t)(((unit_heads(i) + 15u) / 16u) * 16u) : 0;
+}
+
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, u64 n, int32_t v) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ void tile_ptr_kernel(const int32_t* __restrict__ chunk_tile, u32 n_chunks, u32 n_tiles, int32_t* __restrict__ tile_ptr) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
@@ -811,7 +941,7 @@ extern "C" int rgcn_plan_build_begin(const rgcn_graph_t* g, const float* w, int 
         tile = ((node_end - node_begin + 15) / 16) * 16;
     }
     if (tile <= 0 || (tile % 16) != 0 || (tile > 32768 && layout != 2) || (chunk != 64 && chunk != 128)) return RGCN_ERR_PLAN;
-    if (layout != 0 && layout != 2 && !((layout == 1 || layout == 3) && chunk == 128)) return RGCN_ERR_PLAN;
+    if (layout != 0 && layout != 2 && !((layout == 1 || layout == 3) && chunk == 128) && !(layout == 5 && chunk == 64)) return RGCN_ERR_PLAN;
     // (node_begin need not be a tile multiple: tiles count from node_begin.  Callers that want a rank's tiles to BE the
     // single-rank tiles -- bit-identical outputs -- align their ranges themselves: scaling_rgcn_training_amd/dist.py)
     if (node_begin < 0 || node_end <= node_begin || node_end > g->num_nodes) return RGCN_ERR_PLAN;
@@ -913,7 +1043,7 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     hipLaunchKernelGGL(fill_slots_kernel, dim3(grid_for(n_slots)), dim3(256), 0, s, n_slots, bs.n_nodes, bs.tile, slot_src, slot_w, dstl);
     u32* split = ws.scan_a;       // cut position of every chunk (layout 1); n_chunks <= nmax
     // relation-major units: layout 0's dealing inside the one tile; layout 3: layout 0, then compact_runs_kernel
-    const u32 placement = (bs.layout == 2 || bs.layout == 3) ? 0u : bs.layout;
+    const u32 placement = (bs.layout == 2 || bs.layout == 3 || bs.layout == 5) ? 0u : bs.layout;
     hipLaunchKernelGGL(chunk_meta_kernel, dim3(grid_for(bs.n_chunks)), dim3(256), 0, s, ws.gch, ws.gstart, ws.gkey, bs.n_groups,
                        bs.n_chunks, bs.chunk, bs.cap, placement, ws.sb.k[bs.ubuf], bs.kl, split, chunk_rel, chunk_cnt, chunk_tile, chunk_flags);
     hipLaunchKernelGGL(place_kernel, dim3(grid_for(bs.n_unique)), dim3(256), 0, s, ws.sb.k[bs.ubuf], ws.sb.v[bs.ubuf], bs.n_unique,
@@ -925,6 +1055,13 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     // (layout 2: chunk_tile is 0 throughout, so tile_ptr comes out as [0, n_chunks, n_chunks, ...]: never walked)
     hipLaunchKernelGGL(tile_ptr_kernel, dim3(grid_for((u64)n_tiles + 1)), dim3(256), 0, s, chunk_tile, bs.n_chunks, n_tiles,
                        (int32_t*)plan->tile_ptr);
+    if (bs.layout == 5) {      // pairs of rows with one (destination, relation, weight) on ONE slot: before the unit list is built
+        if (!plan->slot_src2) return RGCN_ERR_NULL;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for((u64)bs.n_chunks * 8u)), dim3(256), 0, s, (int32_t*)plan->slot_src2, (u64)bs.n_chunks * 8u,
+                           (int32_t)bs.n_nodes);
+        hipLaunchKernelGGL(dw_pairs_kernel, dim3(grid_for(bs.n_chunks, kPairThreads)), dim3(kPairThreads), 0, s, bs.n_chunks, bs.n_nodes, bs.n_own,
+                           chunk_rel, chunk_tile, chunk_cnt, slot_src, slot_w, slot_row, (int32_t*)plan->slot_src2);
+    }
     // ---- the weight-gradient walk: chunks stably re-sorted by relation, cut into 64-slot units ---------------------
     // (the sort reuses the pair buffers: everything read from them above is already enqueued on this stream)
     SortBufs cb = ws.sb;
@@ -946,6 +1083,12 @@ extern "C" int rgcn_plan_build_finish(const rgcn_plan_sizes_t* sizes, void* work
     plan->n_chunks = (int32_t)bs.n_chunks;
     plan->chunk = (int32_t)bs.chunk;
     plan->n_units = (int32_t)bs.n_units;
+    if (bs.layout == 5) {      // units the pairs left over: data-dependent -- this layout's _finish SYNCHRONISES the stream
+        u32 nu = 0;
+        const int st = read_u32(ws.sb.sums + scan_blocks(bs.n_chunks), &nu, s);
+        if (st != 0) return st;
+        plan->n_units = (int32_t)nu;
+    }
     plan->layout = (int32_t)bs.layout;
     plan->chunk_rows = (int32_t)(bs.cap * 16u);
     return (int)hipGetLastError();

@@ -32,6 +32,10 @@ without atomics").  Everything here is torch tensor plumbing and runs on CPU or 
 from __future__ import annotations
 
 import functools
+
+import numpy as np
+from os import environ as _env
+_os_environ_get = _env.get
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
@@ -73,6 +77,8 @@ class TilePlan:
     layout: int = 0       # 0: rows of a group dealt over all its row tiles; 1: team placement (team_placement);
     #                       3: layout 0 with the runs of equal (destination, relation) on one slot each (compact_runs)
     chunk_rows: int = 0   # rows a chunk may hold: 0 / chunk, or 112 (chunk = 128: seven row tiles of rows per chunk)
+    slot_src2: Optional[Tensor] = None    # layout 5 (the tile-major weight-gradient plan): int32 [n_chunks * 8] second rows of the
+                                          # slots 0..3 and 32..35 of every unit (padding: n_nodes), see dw_pairs
     _keep: tuple = field(default=(), repr=False)
 
     @property
@@ -127,6 +133,10 @@ def build_plan(gather: Tensor, scatter: Tensor, rel: Tensor, w: Tensor, n_nodes:
         chunk, cap = 128, 7
     if chunk not in CHUNKS:
         raise ValueError(f"chunk must be one of {CHUNKS} (or {CHUNK_112})")
+    if int(split) == 5:
+        if chunk != 64:
+            raise ValueError("layout 5 (pairs on one slot: the tile-major weight-gradient plan) needs 64-slot chunks")
+        return dw_pairs(build_plan(gather, scatter, rel, w, n_nodes, num_relations, tile, node_begin, node_end, chunk, False))
     if split and chunk != 128:
         raise ValueError("the team placement and the run compaction need 128-slot chunks")
     if int(split) == 3:
@@ -353,6 +363,131 @@ def compact_runs(plan: TilePlan) -> TilePlan:
     return plan
 
 
+def dw_pairs(plan: TilePlan) -> TilePlan:
+    """Twin of ``dw_pairs_kernel`` (csrc/rgcn_plan.hip): a layout-0 plan with 64-slot chunks -> layout 5, the plan the tile-major
+    weight-gradient kernel walks.  d_W_r is a sum over slots of (w x[src])^T g[row]: two rows with ONE (row, weight) -- a pair --
+    take ONE slot if x[src] + x[src2] is formed first.  Group-local: (tile, relation) groups of at most two chunks; runs of equal
+    (row, weight) are cut into pairs; heads = pairs + single rows are dealt back densely, 64 per unit; the head of a pair needs one
+    of the unit's pair places (slots 0..3, and 32..35 once the unit holds more than 32 heads); pairs beyond the group's places stay
+    two single rows.  ``slot_src2[unit * 8 + k]``: the second row of pair place k.  Chunks the group no longer needs get
+    ``chunk_cnt`` 0 and leave ``rel_order``.  Plain loops over the groups: small plans (tests) only."""
+    if plan.chunk != 64 or plan.layout != 0:
+        raise ValueError("dw_pairs wants a layout-0 plan with 64-slot chunks")
+    dev = plan.slot_src.device
+    n_nodes, n_own = plan.n_nodes, plan.n_owned
+    src = plan.slot_src.cpu().numpy().copy()
+    wbits = plan.slot_w.cpu().numpy().copy().view("uint32")
+    row = plan.slot_row.cpu().numpy().copy()
+    cnt = plan.chunk_cnt.cpu().numpy().copy()
+    crel = plan.chunk_rel.cpu().numpy()
+    ctile = plan.chunk_tile.cpu().numpy()
+    nc = plan.n_chunks
+    src2 = np.full(max(nc * 8, 1), n_nodes, dtype=np.int32)
+    c = 0
+    while c < nc:
+        m = 1
+        while c + m < nc and crel[c + m] == crel[c] and ctile[c + m] == ctile[c]:
+            m += 1
+        c0, c = c, c + m
+        if m > 2:
+            continue
+        nt = sum(int(cnt[c0 + i]) // 16 for i in range(m))
+        if nt == 0:
+            continue
+        base = c0 * 64
+        rows = []
+        for j in range(nt * 16):
+            tt = j % nt
+            sl = base + (tt // 4) * 64 + (tt % 4) * 16 + j // nt
+            if int(src[sl]) == n_nodes:
+                break
+            rows.append((int(src[sl]), int(row[sl]), int(wbits[sl])))
+        n = len(rows)
+        runs, j = [], 0
+        while j < n:
+            ln = 1
+            while j + ln < n and rows[j + ln][1:] == rows[j][1:]:
+                ln += 1
+            runs.append((j, ln))
+            j += ln
+        pairs = sum(ln // 2 for _, ln in runs)
+        if pairs == 0:
+            continue
+        heads = n - pairs
+
+        def unit_heads(u):
+            return min(64, heads - 64 * u)
+
+        def places(u):
+            nu = unit_heads(u)
+            return min(4, nu) + (min(4, nu - 32) if nu > 32 else 0)
+
+        while pairs > sum(places(u) for u in range((heads + 63) // 64)):
+            pairs -= 1
+            heads += 1
+        units = (heads + 63) // 64
+        pairs_in, left = [0, 0], pairs
+        for u in range(units):
+            pairs_in[u] = min(left, places(u))
+            left -= pairs_in[u]
+        src[base:base + m * 64] = n_nodes
+        wbits[base:base + m * 64] = 0
+        row[base:base + m * 64] = n_own
+
+        def is_pair_place(u, sl):
+            if sl < 4:
+                return sl < pairs_in[u]
+            if 32 <= sl < 36:
+                return sl - 28 < pairs_in[u]
+            return False
+
+        pair_left, next_pair, next_single, single_u = pairs, [0, 0], [0, 0], 0
+        for j0, ln in runs:
+            k = 0
+            while k < ln:
+                as_pair = k + 1 < ln and pair_left > 0
+                if as_pair:
+                    u = 0 if next_pair[0] < pairs_in[0] else 1
+                    kk = next_pair[u]
+                    next_pair[u] += 1
+                    sl = kk if kk < 4 else 28 + kk
+                    pair_left -= 1
+                else:
+                    u = single_u
+                    while True:
+                        while next_single[u] < unit_heads(u) and is_pair_place(u, next_single[u]):
+                            next_single[u] += 1
+                        if next_single[u] < unit_heads(u):
+                            break
+                        u += 1
+                        single_u = u
+                    sl = next_single[u]
+                    next_single[u] += 1
+                g = base + u * 64 + sl
+                src[g], row[g], wbits[g] = rows[j0 + k]
+                if as_pair:
+                    src2[(c0 + u) * 8 + (sl if sl < 4 else sl - 28)] = rows[j0 + k + 1][0]
+                    k += 2
+                else:
+                    k += 1
+        for i in range(m):
+            cnt[c0 + i] = (unit_heads(i) + 15) // 16 * 16 if i < units else 0
+    plan.slot_src = torch.from_numpy(src).to(dev)
+    plan.slot_w = torch.from_numpy(wbits.view("float32")).to(dev)
+    plan.slot_row = torch.from_numpy(row).to(dev)
+    plan.chunk_cnt = torch.from_numpy(cnt).to(dev)
+    plan.slot_src2 = torch.from_numpy(src2).to(dev)
+    if plan.slot_dstl is not None:
+        plan.slot_dstl = None          # (host-side checks of the forward plans only)
+    # the unit list: non-empty 64-slot units, relation-major then tile -- as build_plan emits it, over the new counts
+    order_key = plan.chunk_rel.to(torch.int64) * max(plan.n_tiles, 1) + plan.chunk_tile.to(torch.int64)
+    chunk_order = torch.sort(order_key, stable=True)[1]
+    used = plan.chunk_cnt.to(torch.int64)[chunk_order] > 0
+    plan.rel_order = chunk_order[used].to(torch.int32)
+    plan.layout = 5
+    return plan
+
+
 def team_placement(dstl: Tensor, gcnt: Tensor, grp_of_edge: Tensor, rank: Tensor, chunk_base: Tensor,
                    grp_of_chunk: Tensor, idx_in_grp: Tensor):
     """Layout 1 (128-slot chunks): chunk c of a group takes the group's sorted rows [128 c, 128 c + 128) -- n_c of them, on
@@ -467,6 +602,7 @@ def padded_width(w: int) -> int:
 # (exact fp32: 10.15 ms where the model says 8.6; bf16 x 3: 8.4 ms where its model -- 1,800 cycles per chunk, 420 per row tile,
 # DESIGN.md 8.0f -- says 9.2)
 _KERNEL_MODEL = {"fp32": (800.0, 650.0, 1.18), "bf16x3": (1800.0, 420.0, 0.91)}
+DW_PLAN_LAYOUT = int(_os_environ_get("RGCN_DW_PLAN_LAYOUT", "5"))      # 5: pairs on one slot (round 4); 0: one slot per row
 P3_MAX_TILE = 224          # rgcn_tile3p_kernel: two 48 KiB ring slots (any 128-slot chunk) + the fp32 accumulator in 160 KiB
 P3_MAX_TILE_112 = 272      # ... two 42 KiB slots (chunks of at most 112 rows: CHUNK_112)
 
@@ -621,6 +757,8 @@ def _device_plan(graph, w, transposed: bool, n_nodes: int, num_relations: int, t
     if aligned and node_begin % tile != 0:       # forward / dX plans of a rank: its tiles must be the single-rank tiles
         raise ValueError("node_begin must be a multiple of the tile size")
     ps, a, n_edges = _lib.plan_build(graph, w, transposed, node_begin, node_end, tile, chunk, ws, split)
+    if int(split) == 5:          # the pairs left fewer units than _begin sized rel_order for
+        a["rel_order"] = a["rel_order"][:int(ps.n_units)]
     plan = TilePlan(n_nodes=n_nodes, node_begin=node_begin, node_end=node_end, num_relations=num_relations, tile=tile,
                     chunk=int(ps.chunk), n_tiles=int(ps.n_tiles), n_chunks=int(ps.n_chunks), n_edges=n_edges, slot_dstl=None,
                     layout=int(split), chunk_rows=int(ps.chunk_rows), **a)
@@ -702,14 +840,15 @@ def build_graph_plans_device(edge_index: Tensor, edge_type: Tensor, n_nodes: int
             # be a multiple of THAT tile -- the sums of a partitioned d_weight differ in order from the single-rank ones anyway)
             t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
             if num_relations <= max_rel:
-                gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, fb, fe, ws, False, aligned=False)
+                # (layout 5: the two rows of a (destination, relation) pair on one slot -- dw_pairs / dw_pairs_kernel)
+                gp.dw = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, fb, fe, ws, DW_PLAN_LAYOUT, aligned=False)
                 gp.dw_walk = _lib.dw_tiles_walk(_lib.plan_struct(gp.dw), edge_type.device)
         out.append(gp)
     if rank_dw_range is not None and extras is not None and paths[0] != "ep":
         t_dw, walkers, max_rel = _lib.dw_tiles_geometry()
         if num_relations <= max_rel:
             if rank_dw_range[1] > rank_dw_range[0]:
-                pl = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, rank_dw_range[0], rank_dw_range[1], ws, False, aligned=False)
+                pl = _device_plan(graph, w, False, n_nodes, num_relations, t_dw, 64, rank_dw_range[0], rank_dw_range[1], ws, DW_PLAN_LAYOUT, aligned=False)
                 extras["dw_rank"] = (pl, _lib.dw_tiles_walk(_lib.plan_struct(pl), edge_type.device))
             else:
                 extras["dw_rank"] = (None, None)      # an empty range (fewer tiles than ranks): this rank adds zeros

@@ -48,6 +48,12 @@ def emulate_dw(plan, x, g_owned, n_rel_all, din, dout):
         rows = np.arange(64 * u, 64 * u + n)
         seen[rows] = True
         sel = rows[valid[rows]]
-        dw[crel[chunk]] += (x[src[sel]] * w[sel, None]).T @ g[node[sel]]
+        xs = x[src[sel]].copy()
+        if getattr(plan, "slot_src2", None) is not None:      # plan layout 5: the second row of a pair, added before the product
+            s2 = plan.slot_src2.cpu().numpy().astype(np.int64)[8 * u:8 * u + 8]
+            for k_, pos in enumerate((0, 1, 2, 3, 32, 33, 34, 35)):
+                if s2[k_] < plan.n_nodes:
+                    xs[np.nonzero(sel == 64 * u + pos)[0][0]] += x[s2[k_]]
+        dw[crel[chunk]] += (xs * w[sel, None]).T @ g[node[sel]]
     assert not (valid & ~seen).any(), "rel_order misses slots"
     return dw

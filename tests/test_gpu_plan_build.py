@@ -31,7 +31,7 @@ def _compare(ei, et, n, r, tile, chunk, aggr="mean", fr=None, br=None, split=Fal
         for f in ("n_nodes", "node_begin", "node_end", "num_relations", "tile", "chunk", "n_tiles", "n_chunks", "n_edges", "n_units",
                   "layout", "chunk_rows"):
             assert getattr(a, f) == getattr(b, f), (name, f, getattr(a, f), getattr(b, f))
-        for f in ARRAYS:
+        for f in ARRAYS + (("slot_src2",) if int(split) == 5 else ()):
             x, y = getattr(a, f), getattr(b, f)
             assert x.dtype == y.dtype and x.shape == y.shape, (name, f, x.dtype, y.dtype, x.shape, y.shape)
             if not torch.equal(x, y):
@@ -106,3 +106,24 @@ def test_plan_build_10m_edges_bit_identical_and_timed():
     dt = time.perf_counter() - t0
     print(f"device plan build, 10M edges: {dt * 1e3:.1f} ms")
     assert dt < 0.25
+
+
+@pytest.mark.parametrize("n,e,r,skew", [(6000, 60000, 32, False), (3000, 40000, 16, True), (2000, 9000, 8, False), (20000, 200000, 32, False),
+                                        (40, 0, 2, False)])
+def test_dw_pair_plan_matches_torch(n, e, r, skew):
+    """plan layout 5 (the tile-major weight-gradient plan: the two rows of a (destination, relation, weight) pair on ONE slot,
+    the second row in slot_src2; csrc/rgcn_plan.hip dw_pairs_kernel) against its torch twin plan.dw_pairs: every array, the unit
+    list and the unit count bit-identical; duplicate triples (weights that differ inside a run) and hubs (groups left alone)"""
+    from scaling_rgcn_training_amd import _lib
+    t_dw = _lib.dw_tiles_geometry()[0]
+    if e:
+        ei, et = O.synthetic_graph(n, e, r, seed=n + e, skew=skew)
+        ei[:, 10:40] = ei[:, 50:80]                # duplicate triples: merged slots of weight 2 / c inside runs of weight 1 / c
+        et[10:40] = et[50:80]
+    else:
+        ei, et = torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.long)
+    plans = _compare(ei.to(DEV), et.to(DEV), n, r, t_dw, 64, split=5)
+    for p in (plans.fwd, plans.bwd):
+        assert p.layout == 5 and p.slot_src2.numel() == max(p.n_chunks * 8, 1)
+        if e >= 40000 and not skew:
+            assert int((p.slot_src2 < n).sum()) > 0, "no pair was formed: the case tests nothing"
