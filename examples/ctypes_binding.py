@@ -1,4 +1,4 @@
-"""The whole reference-side binding of librgcn_mi355x.so (ABI v12) in one file: ctypes + torch tensors as device memory,
+"""The whole reference-side binding of librgcn_mi355x.so (ABI v17) in one file: ctypes + torch tensors as device memory,
 nothing imported from this repository's Python package.  This is what a maintainer of the reference would drop next to
 model/layers.py to replace ``torch_geometric.nn.RGCNConv`` (model/layers.py:7, call sites :21,23) and what autograd
 derives from it (model/modelTrainer.py:66) without taking the package; ``scaling_rgcn_training_amd/_lib.py`` + ``conv.py``
