@@ -661,7 +661,11 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
             if (it + 1 == tend && it + 1 < nch) {
                 // this chunk closed a tile: the consumer threads store it and reset the accumulator; the producers wait at
                 // the same extra barrier with the next tile's first chunks already in LDS / in flight
+#ifndef RGCN_P3_ABL_NOEPI     // timing-only build: what a tile boundary costs
+                // (round 4, profiles/r04w_*: the producer waves storing too, or no vmcnt(0) behind the stores: no change -- what is
+                // left of a tile boundary, ~0.26 ms per launch, is the LDS pass, the 2.56 GB of output and two barriers)
                 tile_epilogue<LDO, true>(a, out_lds, tile_cur, cw * 64 + lane, 64 * kConsumers);
+#endif
                 ++tile_cur;
                 tend = ldc(a.tile_ptr, tile_cur + 1) - c0;
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the epilogue's memory operations here, once per tile

@@ -42,6 +42,65 @@ constexpr int kTileConsumerWaves = 4;
 // REINIT: every element is also reset to the bias for the NEXT tile of a workgroup that walks several tiles (each thread
 // resets exactly the elements it has just read; columns beyond the width never leave zero, the dummy row is never stored).
 // tid / nthreads: the calling threads' rank and count (all 512, or the 256 consumer threads between two tiles).
+struct EpiRows {
+    float* lp;            // this thread's piece of the first row in the LDS tile
+    float* gp;            // ... in the output
+    const float* mp;      // ... in the mask rows, or NULL
+    int lstep;            // floats between two rows of this thread, LDS
+    size_t gstep, mstep;  // ... output, mask
+    int n;                // rows of this thread
+    f32x4 bfix;           // what the LDS piece is reset to (REINIT)
+};
+
+// one thread's rows of the tile store: four pieces in flight (four LDS reads, then four stores), no index arithmetic
+template <bool REINIT, int ACT, bool MASK>
+__device__ __forceinline__ void epilogue_rows(EpiRows e) {
+    auto finish = [&](f32x4 v, f32x4 m) {
+        if constexpr (ACT == RGCN_ACT_RELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : 0.f;
+        }
+        if constexpr (MASK) {
+            // v = m > 0 ? v : 0 through VCC: sixteen compares in flight would want sixteen SGPR pairs, and the kernels that
+            // inline this are at their SGPR limit (spills into VGPR lanes inside their main loops otherwise)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = v[c];
+                asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(t) : "v"(m[c]) : "vcc");
+                v[c] = t;
+            }
+        }
+        return v;
+    };
+    int k = 0;
+    for (; k + 4 <= e.n; k += 4) {
+        f32x4 v[4], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = *(const f32x4*)(e.lp + u * e.lstep);
+            if constexpr (MASK) m[u] = *(const f32x4*)(e.mp + u * e.mstep);
+            else m[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (REINIT) *(f32x4*)(e.lp + u * e.lstep) = e.bfix;
+            *(f32x4*)(e.gp + u * e.gstep) = finish(v[u], m[u]);
+        }
+        e.lp += 4 * e.lstep;
+        e.gp += 4 * e.gstep;
+        if constexpr (MASK) e.mp += 4 * e.mstep;
+    }
+    for (; k < e.n; ++k) {
+        f32x4 v = *(const f32x4*)e.lp, m = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MASK) m = *(const f32x4*)e.mp;
+        if constexpr (REINIT) *(f32x4*)e.lp = e.bfix;
+        *(f32x4*)e.gp = finish(v, m);
+        e.lp += e.lstep;
+        e.gp += e.gstep;
+        if constexpr (MASK) e.mp += e.mstep;
+    }
+}
+
 template <int LDO, bool REINIT>
 __device__ __forceinline__ void tile_epilogue(const TileArgs& a, float* out_lds, int tile, int tid, int nthreads) {
     const int row0 = tile * a.tile;
@@ -60,15 +119,39 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs& a, float* out_lds,
         }
         return b;
     };
-    // a thread meets one column group only when the thread count is a multiple of the groups per row: its bias then
-    // is loaded once, not per element
-    const bool fixed_c4 = REINIT && (nthreads % o4) == 0;
-    f32x4 bfix = {0.f, 0.f, 0.f, 0.f};
-    if (fixed_c4) bfix = bias4(tid % o4);
+    // A thread meets one column group only when the thread count is a multiple of the groups per row (every width whose
+    // o4 is a power of two: 64 -> o4 = 16): its bias is loaded once and its three addresses advance by constants -- one
+    // division per tile instead of one per 16-byte piece.  Round 4: the per-piece index arithmetic made the store of a tile
+    // VALU-bound (~8,000 cycles of a tile's ~115,000 at the headline config, profiles/r04w_*); this loop is bound by the LDS
+    // and the store path.
+    if ((nthreads % o4) == 0 && act != RGCN_ACT_SIGMOID) {      // (sigmoid: the output layer's one launch takes the loop below)
+        const int c4 = tid % o4, r0 = tid / o4, rstep = nthreads / o4;
+        f32x4 bfix = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (REINIT) bfix = bias4(c4);
+        EpiRows e;
+        e.lp = out_lds + r0 * LDO + c4 * 4;
+        e.gp = a.out + (size_t)(row0 + r0) * a.ldo + c4 * 4;
+        e.mp = a.mask != nullptr ? a.mask + (size_t)(row0 + r0) * a.ldm + c4 * 4 : nullptr;
+        e.lstep = rstep * LDO;
+        e.gstep = (size_t)rstep * a.ldo;
+        e.mstep = (size_t)rstep * a.ldm;
+        e.n = rows > r0 ? (rows - r0 + rstep - 1) / rstep : 0;
+        e.bfix = bfix;
+        // the activation and the mask are launch constants: one straight-line loop per combination that occurs
+        if (a.mask != nullptr) {
+            if (act == RGCN_ACT_NONE) epilogue_rows<REINIT, RGCN_ACT_NONE, true>(e);
+            else epilogue_rows<REINIT, RGCN_ACT_RELU, true>(e);
+        } else {
+            if (act == RGCN_ACT_NONE) epilogue_rows<REINIT, RGCN_ACT_NONE, false>(e);
+            else epilogue_rows<REINIT, RGCN_ACT_RELU, false>(e);
+        }
+        return;
+    }
+    // any other width (o4 = 3, 5, ...: the narrow / wide kernels): a thread's pieces change columns from row to row
     for (int i = tid; i < rows * o4; i += nthreads) {
         const int r = i / o4, c4 = i - r * o4;
         f32x4 v = *(const f32x4*)(out_lds + r * LDO + c4 * 4);
-        if constexpr (REINIT) *(f32x4*)(out_lds + r * LDO + c4 * 4) = fixed_c4 ? bfix : bias4(c4);
+        if constexpr (REINIT) *(f32x4*)(out_lds + r * LDO + c4 * 4) = bias4(c4);
         if (act == RGCN_ACT_RELU) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : 0.f;

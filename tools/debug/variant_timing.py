@@ -24,6 +24,7 @@ def child():
         del key
     tile, chunk = P.choose_layout(n, e, r, 64, 64)
     tile = int(os.environ.get("VT_TILE", tile))
+    chunk = int(os.environ.get("VT_CHUNK", chunk))
     kflags = int(os.environ.get("VT_FLAGS", 0))
     plans = P.build_graph_plans_device(ei, et, n, r, tile, chunk=chunk, dw_tiles="dw" in which, split=int(os.environ.get("VT_SPLIT", "0")))
     del ei, et
