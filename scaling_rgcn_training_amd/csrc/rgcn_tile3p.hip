@@ -368,10 +368,7 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
     const int c0 = ldc(a.tile_ptr, tile0);
     const int nch = ldc(a.tile_ptr, tile1) - c0;
 
-    for (int i = tid; i < (a.tile + 1) * LDO; i += kThreadsAll) {
-        const int col = i % LDO;
-        out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
-    }
+    tile_init<LDO>(a, out_lds, tid, kThreadsAll);
 
     constexpr bool kRoleMap = RGCN_P3_ROLEMAP && kConsumers == 4;
     const bool is_consumer = kRoleMap ? (wave & 2) == 0 : wave >= 4;

@@ -42,6 +42,26 @@ constexpr int kTileConsumerWaves = 4;
 // REINIT: every element is also reset to the bias for the NEXT tile of a workgroup that walks several tiles (each thread
 // resets exactly the elements it has just read; columns beyond the width never leave zero, the dummy row is never stored).
 // tid / nthreads: the calling threads' rank and count (all 512, or the 256 consumer threads between two tiles).
+// The accumulator tile of a workgroup's first tile: every row = the bias (columns beyond the width and the pad: zero), row
+// `tile` (the dummy row of padding slots) included.  A thread keeps ONE 16-byte column piece and walks rows: one bias load per
+// thread where the per-element form had one per element (a dependent global load in each of its ~36 iterations: ~10 us at
+// the start of every workgroup, a fifth of a launch on graphs of a few hundred tiles).
+template <int LDO>
+__device__ __forceinline__ void tile_init(const TileArgs& a, float* out_lds, int tid, int nthreads) {
+    static_assert(LDO % 4 == 0, "16-byte pieces");
+    constexpr int P = LDO / 4;                 // pieces per row
+    const int per = nthreads / P;              // rows written per pass
+    if (tid >= per * P) return;
+    const int c4 = tid % P, r0 = tid / P;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = c4 * 4 + c < a.dout ? a.bias[c4 * 4 + c] : 0.f;
+    }
+    float* p = out_lds + r0 * LDO + c4 * 4;
+    for (int r = r0; r <= a.tile; r += per, p += per * LDO) *(f32x4*)p = b;
+}
+
 struct EpiRows {
     float* lp;            // this thread's piece of the first row in the LDS tile
     float* gp;            // ... in the output

@@ -264,10 +264,7 @@ __global__ void __launch_bounds__(kTileThreads, RGCN_TILE_WAVES) rgcn_tile_kerne
     const int c0 = ldc(a.tile_ptr, tile0);
     const int nch = ldc(a.tile_ptr, tile1) - c0;
 
-    for (int i = tid; i < (a.tile + 1) * LDO; i += kTileThreads) {
-        const int col = i % LDO;
-        out_lds[i] = (a.bias != nullptr && col < a.dout) ? a.bias[col] : 0.f;
-    }
+    tile_init<LDO>(a, out_lds, tid, kTileThreads);
 
     // The two roles run DIFFERENT loops that meet only at s_barrier (a hardware arrival counter: it
     // does not care which instruction a wave arrives from; both loops execute 1 + nch barriers).
