@@ -631,6 +631,12 @@ __global__ void __launch_bounds__((P3Cfg<TEAMS, NCT>::kThreads), (P3Cfg<TEAMS, N
                 for (int t = 0; t < n; ++t) process_slow(t, (flags >> t) & 1);
             }
             P3S(t2s);
+            // (Round 4, tried: the chunk loop unrolled by two with two register sets that trade places, so that these 24 v_mov
+            // go.  With the prefetch where it is, the register allocator copies the set right behind the loads -- before they
+            // have landed -- wherever a live range is split at the back edge: wrong results.  With the prefetch at the top of
+            // the iteration and the wait down here, correct and copy-free, but 7.61 -> 7.75 ms: six loads and their addresses in
+            // front of the first operand read cost more than the copies; behind the first MFMA block: 8.37 ms.
+            // profiles/r04z_weight_sets_timing.txt)
             if (swap_b) {
                 wait_vmcnt<0>();                     // the asm prefetch (this wave's only vector-memory traffic)
 #pragma unroll
