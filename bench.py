@@ -55,7 +55,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_16x16x4_f32), 155 measured
 # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE, then WRITE_SIZE; gfx950 correction): counters
 # cannot be read inside this process, so `roofline.traffic` quotes the newest committed pass and names it
-PMC_TRAFFIC_FILE = os.environ.get("RGCN_PMC_TRAFFIC_FILE", "r04u_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.environ.get("RGCN_PMC_TRAFFIC_FILE", "r04x_pmc_traffic.json")
 HEADLINE = (10_000_000, 100_000_000, 32, 64)
 # (name, nodes, edges, relations R', in, out, num_bases): the smaller rungs of SURVEY.md 8d and the shapes of the reference's
 # own datasets (model/modelTrainer.py:78,92: R' = 2R + 1 = 89 / 45 / ~267; MUTAG's edge count is a guess -- the file is not
