@@ -177,6 +177,60 @@ def test_full_size_sampled_rows_match_oracle(big):
             assert abs(ms) <= 2.0 * abs(me) + 0.1 * ee, f"d_weight[{r}]: mean signed error {ms:+.3e} (bf16 x 3) vs {me:+.3e} (exact fp32): a bias"
 
 
+def test_full_size_every_row_by_a_second_evaluation_and_column_checksums(big):
+    """The sampled rows above leave ~10M rows to the properties below ("what's weak").  Two whole-output checks:
+    (a) EVERY element of the forward and of dX against a second evaluation that shares nothing with the first but the input:
+        the exact-fp32 tile kernel (v_mfma_f32_16x16x4_f32) on layout-0 plans of its own tile size, where the module's default is
+        the bf16 x 3 kernel on layout-3 plans with 112-row chunks (uniform graph) or the edge-parallel path (hub graph) -- an
+        error would have to be made twice, by different kernels walking different plans, to pass;
+    (b) the column sums of the whole output in float64 against their closed form from the edge list by plain torch ops:
+        sum_dst out = sum_r (sum_{e in r} x[src_e] / c[dst_e, r]) W_r + (sum_i x_i) root + N bias, and the same for dX with dOut and
+        W_r^T -- every edge exactly once, with the reference's mean normaliser (duplicates counted)."""
+    from scaling_rgcn_training_amd.conv import RGCNConv
+    conv, x, ei, et, dg, dev = big["conv"], big["x"], big["ei"], big["et"], big["dg"], big["dev"]
+    out, dx = big["out"], big["dx"]
+    # ---- (a)
+    other = RGCNConv(D, D, R).to(dev)
+    other.split_producers, other.merge_runs, other.path = False, False, "ring"
+    with torch.no_grad():
+        for q, v in zip(other.parameters(), conv.parameters()):
+            q.copy_(v)
+    xg = x.clone().requires_grad_(True)
+    out2 = other(xg, ei, et)
+    out2.backward(dg)
+    plans = other._plans(xg, ei, et)
+    assert plans.fwd is not None and plans.fwd.layout == 0 and plans.bwd.layout == 0, "the second evaluation walks layout-0 plans"
+    for name, got, ref in (("out", out, out2.detach()), ("d_x", dx, xg.grad)):
+        diff = (got - ref).abs()
+        bound = 1e-5 + 1e-5 * ref.abs()
+        if big["kind"] == "skew":      # rows that sum millions of terms in fp32, in two different orders
+            bound = bound * 10.0
+        worst = float((diff - bound).max())
+        assert worst <= 0.0, f"{name}: {int((diff > bound).sum())} of {diff.numel()} elements differ by more than the bound (worst excess {worst:.3e})"
+        del diff, bound
+    del out2, xg, other, plans
+    torch.cuda.empty_cache()
+    # ---- (b)
+    key = ei[1] * R + et
+    cnt = torch.bincount(key, minlength=N * R)
+    w_e = 1.0 / cnt[key].double()
+    del key, cnt
+    W, root, bias = conv.weight.detach().double(), conv.root.detach().double(), conv.bias.detach().double()
+    s_f = torch.zeros(R, D, dtype=torch.float64, device=dev)
+    s_b = torch.zeros(R, D, dtype=torch.float64, device=dev)
+    for lo in range(0, E, 1 << 22):
+        sl = slice(lo, lo + (1 << 22))
+        s_f.index_add_(0, et[sl], x[ei[0][sl]].double() * w_e[sl, None])
+        s_b.index_add_(0, et[sl], dg[ei[1][sl]].double() * w_e[sl, None])
+    want_f = torch.einsum("rk,rkn->n", s_f, W) + x.double().sum(0) @ root + N * bias
+    want_b = torch.einsum("rn,rkn->k", s_b, W) + dg.double().sum(0) @ root.t()
+    for name, got, want in (("out", out, want_f), ("d_x", dx, want_b)):
+        col = got.double().sum(0)
+        tol = 1e-6 * got.double().abs().sum(0) + 1e-3       # ~ sqrt(N) roundings of size u |value| each would be far below this
+        err = (col - want).abs()
+        assert bool((err <= tol).all()), f"column sums of {name}: worst {float((err / tol).max()):.3f} x the tolerance"
+
+
 def test_full_size_weight_gradients_linear_in_dout(big):
     """d_weight / d_root / d_bias are linear in dOut: grads(2 g) == 2 grads(g) bit for bit (scaling by two is exact in
     binary floating point and every kernel sums in a fixed order), and grads(g1 + g2) == grads(g1) + grads(g2) up to
