@@ -256,39 +256,55 @@ __global__ void edge_keys_kernel(const int64_t* __restrict__ src, int64_t src_st
                                  const float* __restrict__ w, u64 num_edges, int transposed, u32 n_nodes, u32 num_rel,
                                  u32 node_begin, u32 node_end, u32 tile, KeyLayout kl, u32 n_own, u64* __restrict__ keys,
                                  u32* __restrict__ vals, Counters* __restrict__ ctr) {
+    // A wave takes kBatch x 64 consecutive edges, keeps their keys in registers and reserves room for all of them with ONE
+    // atomic on the shared counter (one atomic per 64 edges was 1.6M serialised atomics on one address at 100M edges: 17.8 ms of
+    // a kernel that moves 4 GB)
+    constexpr int kBatch = 8;
     const int lane = threadIdx.x & 63;
-    for (u64 e0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) - lane; e0 < num_edges; e0 += (u64)gridDim.x * blockDim.x) {
-        const u64 e = e0 + lane;
-        bool own = false;
-        u64 key = 0;
-        u32 val = 0;
-        if (e < num_edges) {
-            const int64_t s = src[e * src_stride], d = dst[e * dst_stride], t = typ[e * typ_stride];
-            u32 err = 0;
-            if (t < 0 || t >= (int64_t)num_rel) err |= 1u;
-            if (s < 0 || s >= (int64_t)n_nodes || d < 0 || d >= (int64_t)n_nodes) err |= 2u;
-            if (err) {
-                atomicOr(&ctr->error, err);
-            } else {
-                const u32 g = (u32)(transposed ? d : s), sc = (u32)(transposed ? s : d);
-                if (sc >= node_begin && sc < node_end) {
-                    const u32 loc = sc - node_begin;
-                    own = true;
-                    key = kl.pack(loc / tile, (u32)t, loc % tile, g);
-                    val = __float_as_uint(w[e]);
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 e0 = wave * (kBatch * 64); e0 < num_edges; e0 += waves * (kBatch * 64)) {
+        u64 key[kBatch];
+        u32 val[kBatch];
+        u64 mask[kBatch];
+        u32 total = 0;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const u64 e = e0 + (u64)k * 64 + lane;
+            bool own = false;
+            key[k] = 0;
+            val[k] = 0;
+            if (e < num_edges) {
+                const int64_t sv = src[e * src_stride], d = dst[e * dst_stride], t = typ[e * typ_stride];
+                u32 err = 0;
+                if (t < 0 || t >= (int64_t)num_rel) err |= 1u;
+                if (sv < 0 || sv >= (int64_t)n_nodes || d < 0 || d >= (int64_t)n_nodes) err |= 2u;
+                if (err) {
+                    atomicOr(&ctr->error, err);
+                } else {
+                    const u32 g = (u32)(transposed ? d : sv), sc = (u32)(transposed ? sv : d);
+                    if (sc >= node_begin && sc < node_end) {
+                        const u32 loc = sc - node_begin;
+                        own = true;
+                        key[k] = kl.pack(loc / tile, (u32)t, loc % tile, g);
+                        val[k] = __float_as_uint(w[e]);
+                    }
                 }
             }
+            mask[k] = __ballot(own);
+            total += (u32)__popcll(mask[k]);
         }
-        const u64 m = __ballot(own);
-        if (m == 0) continue;
+        if (total == 0) continue;
         u32 base = 0;
-        const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(&ctr->owned_edges, (u32)__popcll(m));
-        base = __shfl(base, leader);
-        if (own) {
-            const u32 pos = n_own + base + (u32)__popcll(m & ((1ull << lane) - 1ull));
-            keys[pos] = key;
-            vals[pos] = val;
+        if (lane == 0) base = atomicAdd(&ctr->owned_edges, total);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if ((mask[k] >> lane) & 1ull) {
+                const u32 pos = n_own + base + (u32)__popcll(mask[k] & ((1ull << lane) - 1ull));
+                keys[pos] = key[k];
+                vals[pos] = val[k];
+            }
+            base += (u32)__popcll(mask[k]);
         }
     }
 }
