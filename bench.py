@@ -270,6 +270,8 @@ def emulate_world(weight, root, ei, et, x, dg, dev, world, single_step_ms, steps
                 b_ms = statistics.median(b.elapsed_time(c) for a, b, c in evs)
                 own_rows = sum(dctx.node_range(s_, n)[1] - dctx.node_range(s_, n)[0] for s_ in range(dctx.pieces))
                 row = {"world": world, "pieces": dctx.pieces, "exchange": exch, "rank": rk, "heaviest_rank": heaviest,
+                       "piece_tiles": [(dctx.bounds[s_ * world + 1] - dctx.bounds[s_ * world]) // max(1, plans.pieces[0].fwd.tile if plans.pieces[0].fwd is not None else 1)
+                                       for s_ in range(dctx.pieces)],
                        "rank_share_ms": f_ms + b_ms, "forward_ms": f_ms, "backward_ms": b_ms,
                        "single_gpu_step_over_world_ms": single_step_ms / world,
                        "share_over_ideal": (f_ms + b_ms) / (single_step_ms / world),
@@ -286,11 +288,22 @@ def emulate_world(weight, root, ei, et, x, dg, dev, world, single_step_ms, steps
                 ld = (d + 3) // 4 * 4
                 per_link = recv_rows * ld * 4 / max(1, world - 1)
                 pred = {}
+                # the pieces' shares of the rank's rows (dist.piece_tiles: pieces of whole launch rounds are not equal)
+                fr = [(dctx.node_range(s_, n)[1] - dctx.node_range(s_, n)[0]) / max(1, own_rows) for s_ in range(dctx.pieces)]
+
+                def wire_end(k_ms, c_ms):
+                    # kernels of piece s, then its exchange on the collective's stream (one exchange at a time), under the kernels
+                    # of the pieces behind it: when the last exchange ends.  Equal pieces: max(K + c / p, K / p + c).
+                    t_k = t_c = 0.0
+                    for f_ in fr:
+                        t_k += k_ms * f_
+                        t_c = max(t_c, t_k) + c_ms * f_
+                    return t_c
+
                 for name, rate in (("153_GBps", 153e9), ("76_GBps", 76e9)):
                     c_ms = per_link / rate * 1e3
-                    p_ = dctx.pieces
-                    t_f = max(f_ms + c_ms / p_, f_ms / p_ + c_ms)
-                    t_b = max(b_ms, f_ms / p_ + c_ms)
+                    t_f = wire_end(f_ms, c_ms)
+                    t_b = max(b_ms, wire_end(f_ms, c_ms))      # (the dX launches take about what the forward ones take)
                     pred[name] = {"ms_per_gather_on_the_wire": c_ms, "step_ms": t_f + t_b, "speedup_over_1_gpu": single_step_ms / (t_f + t_b)}
                 row["bytes_per_link_per_gather"] = per_link
                 row["predicted"] = pred

@@ -111,7 +111,7 @@ class DistContext:
     ``stats`` counts what the collectives moved (bench.py reports it per step)."""
 
     def __init__(self, group, rank: int, world: int, piece_rows: int, pieces: int, bounds=None, exchange: str = "full",
-                 emulate: bool = False, split_hubs: bool = True):
+                 emulate: bool = False, split_hubs: bool = True, uniform: Optional[bool] = None):
         if exchange not in ("full", "needed"):
             raise ValueError("exchange must be 'full' or 'needed'")
         self.group, self.rank, self.world = group, rank, world
@@ -120,10 +120,17 @@ class DistContext:
         # edge-parallel pieces: the heavy (node, relation) segments of the whole graph are summed by ALL ranks, an equal share of
         # their rows each, and one small all-reduce completes the sums (eplan.SharedHeavy) -- a hub no longer belongs to one rank
         self.split_hubs = split_hubs
-        self.uniform = bounds is None
-        self.piece_rows = piece_rows if self.uniform else None
-        self.bounds = [i * piece_rows for i in range(pieces * world + 1)] if self.uniform else [int(b) for b in bounds]
+        # uniform: the blocks of ONE piece are equal (one in-place all-gather per piece); ``bounds`` given with uniform = True:
+        # pieces of different lengths (dist.piece_tiles: whole launch rounds), still equal blocks inside each
+        self.uniform = (bounds is None) if uniform is None else bool(uniform)
+        self.bounds_equal = bounds is None                 # every block of every piece has ``piece_rows`` rows
+        self.piece_rows = piece_rows if bounds is None else None
+        self.bounds = [i * piece_rows for i in range(pieces * world + 1)] if bounds is None else [int(b) for b in bounds]
         assert len(self.bounds) == pieces * world + 1
+        if self.uniform:
+            for s_ in range(pieces):
+                sizes = {self.bounds[s_ * world + r + 1] - self.bounds[s_ * world + r] for r in range(world)}
+                assert len(sizes) == 1, "uniform cut: the blocks of a piece are equal"
         self.stats = {"all_gather": 0, "all_gather_bytes": 0, "all_reduce": 0, "all_reduce_bytes": 0,
                       "wait_events": []}
         self.time_waits = False     # bench.py: HIP events around the waits on the collectives, piece by piece

@@ -35,6 +35,34 @@ def piece_rows(n_nodes: int, tile: int, world: int, pieces: int) -> int:
     return ((n_tiles + world * pieces - 1) // (world * pieces)) * tile
 
 
+CU_ROUND = 256   # workgroups one launch round of a tile kernel holds on an MI355X (one workgroup per CU: their LDS)
+
+
+def piece_tiles(n_tiles: int, world: int, pieces: int):
+    """Tiles per block of every piece of the uniform cut (all blocks of ONE piece are equal: one in-place all-gather per piece).
+    Equal pieces, unless a piece is a few launch rounds long: a launch of 1,149 one-tile workgroups takes FIVE rounds of 256 where
+    its tiles fill 4.5, so four equal pieces of a rank's 4,596 tiles (headline config, world 8) walk 20 rounds where one piece
+    walks 18 (measured on the emulated rank: forward 0.96 -> 1.10 ms).  Then every piece but ONE is a whole number of
+    rounds and the short one comes FIRST: where the wire is what binds (2.09 ms per gather at 153 GB/s per link against ~1 ms
+    of kernels at world 8) a direction ends when the first piece's kernels and then all the exchanges have run, so the first
+    piece is the one to keep short (fewer pieces if nothing is left for it).
+    Larger pieces (>= 16 rounds: the kernels walk several tiles per workgroup there) and smaller ones (< 1 round) stay equal."""
+    per_rank = (n_tiles + world - 1) // world
+    eq = (per_rank + pieces - 1) // pieces
+    if pieces == 1 or eq < CU_ROUND or eq >= 16 * CU_ROUND:
+        return [eq] * pieces
+    b = (eq + CU_ROUND - 1) // CU_ROUND * CU_ROUND
+    out, left = [], per_rank
+    while left > 0 and len(out) < pieces:
+        t = left if len(out) == pieces - 1 else min(b, left)
+        out.append(t)
+        left -= t
+    if len(out) > 1 and out[-1] < CU_ROUND // 8:      # a piece of a few tiles is not worth its launches and its collective
+        last = out.pop()
+        out[-1] += last
+    return out[::-1]
+
+
 def tile_costs(edge_index: Tensor, n_nodes: int, tile: int) -> Tensor:
     """float64 [n_tiles]: rows a rank that owns the tile walks per layer step -- the edges INTO its nodes (forward plan), the
     edges OUT OF them (transposed plan) and the two root pseudo edges per node."""
@@ -95,9 +123,18 @@ def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge
         return None
     n_tiles = (n_nodes + tile - 1) // tile
     pieces = max(1, min(pieces, n_tiles // world if n_tiles >= world else 1))
-    pr = piece_rows(n_nodes, tile, world, pieces)
     kw = {"exchange": exchange, "emulate": emulate is not None, "split_hubs": split_hubs}
-    ctx = DistContext(group, rank, world, pr, pieces, **kw)
+    pt = piece_tiles(n_tiles, world, pieces)
+    if len(set(pt)) == 1 and len(pt) == pieces:
+        ctx = DistContext(group, rank, world, piece_rows(n_nodes, tile, world, pieces), pieces, **kw)
+    else:       # pieces of whole launch rounds: the blocks of one piece are equal, the pieces are not
+        pieces = len(pt)
+        bounds, at = [0], 0
+        for t in pt:
+            for _ in range(world):
+                at += t * tile
+                bounds.append(at)
+        ctx = DistContext(group, rank, world, 0, pieces, bounds, uniform=True, **kw)
     if edge_index is not None and balance is not False:
         ei_cost, shared_rows = edge_index, 0.0
         if split_hubs and edge_type is not None and edge_index.shape[1] > 0:
@@ -121,7 +158,12 @@ def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge
         bc = block_costs(costs, ctx.bounds, tile)
         # (the uniform cut pads its last blocks past the graph's end: compare the heaviest block with a block's share of the
         # total, not with a mean the empty trailing blocks pull down)
-        if balance or float(bc.max()) > (1.0 + BALANCE_TOLERANCE) * float(costs.sum()) / (pieces * world):
+        # (what has to be equal is the ranks' blocks WITHIN a piece: every block against the cost a block of its piece's length
+        # holds on average -- not against a mean that the padding past the graph's end pulls down)
+        bcv = bc.view(pieces, world)
+        nominal = torch.tensor([float(costs.sum()) * t / n_tiles for t in pt], dtype=torch.float64).view(pieces, 1)
+        uneven = bool((bcv > (1.0 + BALANCE_TOLERANCE) * nominal).any())
+        if balance or uneven:
             ctx = DistContext(group, rank, world, 0, pieces, balanced_bounds(costs, n_nodes, tile, world, pieces), **kw)
             bc = block_costs(costs, ctx.bounds, tile)
         ctx.block_costs = bc.view(pieces, world)

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret, n, e, tile, pieces, skew=False, balance=None):
+def _worker(rank, world, port, ret, n, e, tile, pieces, skew=False, balance=None, cu_round=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,8 +38,14 @@ def _worker(rank, world, port, ret, n, e, tile, pieces, skew=False, balance=None
     x = torch.randn(n, din, generator=g).double()
     dg = torch.randn(n, dout, generator=g).double()
     w_all = np.concatenate([w.numpy(), root.numpy()[None]], 0).astype(np.float64)
+    if cu_round is not None:       # a "launch round" of a few tiles: the pieces-of-whole-rounds cut at test size (dist.piece_tiles)
+        rdist.CU_ROUND = cu_round
     ctx = rdist.make_context(n, tile, pieces=pieces, edge_index=ei, balance=balance)
     assert ctx is not None and ctx.world == world and ctx.rank == rank
+    if cu_round is not None:
+        lens = [ctx.bounds[s_ * world + 1] - ctx.bounds[s_ * world] for s_ in range(ctx.pieces)]
+        assert ctx.uniform and not ctx.bounds_equal and len(set(lens)) > 1, "pieces of different lengths, equal blocks inside each"
+        assert all(l % (cu_round * tile) == 0 for l in lens[1:]) and lens[0] <= lens[-1], "whole rounds, the FIRST piece the short one"
     if balance or skew:
         assert not ctx.uniform, "edge counts of equal node blocks differ by more than 5 %: the cut follows the edges"
         assert all(b % tile == 0 for b in ctx.bounds[:-1]) and ctx.bounds[-1] == n and ctx.bounds == sorted(ctx.bounds)
@@ -119,11 +125,11 @@ def _worker(rank, world, port, ret, n, e, tile, pieces, skew=False, balance=None
     dist.destroy_process_group()
 
 
-def _run(world, n, e, tile, pieces, skew=False, balance=None):
+def _run(world, n, e, tile, pieces, skew=False, balance=None, cu_round=None):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, n, e, tile, pieces, skew, balance)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, n, e, tile, pieces, skew, balance, cu_round)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -162,6 +168,29 @@ def test_four_ranks_edge_balanced_cut_on_a_hub_graph():
 
 def test_eight_ranks_edge_balanced_cut_on_a_hub_graph():
     _run(8, 6000, 60000, 64, 3, skew=True)
+
+
+def test_pieces_of_whole_launch_rounds_two_and_four_ranks():
+    """dist.piece_tiles: where a piece is a few launch rounds long every piece but the first is a whole number of rounds (a
+    launch of 1,149 one-tile workgroups takes five rounds of 256, its tiles fill 4.5) -- pieces of different lengths, one
+    in-place all-gather each.  At test size with a "round" of 3 tiles: 4,000 nodes / tile 16 = 250 tiles, 125 per rank at world
+    2 -> pieces of 26, 33, 33, 33 tiles; the needed-rows exchange and the single-rank comparison as everywhere in this file."""
+    _run(2, 4000, 30000, 16, 4, cu_round=3)
+    _run(4, 4000, 30000, 16, 3, cu_round=4)
+
+
+def test_piece_tiles_rules():
+    from scaling_rgcn_training_amd import dist as rdist
+    assert rdist.piece_tiles(36765, 8, 4) == [756, 1280, 1280, 1280]          # headline config at world 8: 18 rounds, not 20
+    assert rdist.piece_tiles(36765, 4, 4) == [2280, 2304, 2304, 2304]
+    assert rdist.piece_tiles(36765, 2, 4) == [4596] * 4                        # >= 16 rounds per piece: several tiles per workgroup
+    assert rdist.piece_tiles(36765, 8, 1) == [4596]
+    assert rdist.piece_tiles(100, 2, 4) == [13] * 4                            # less than a round: equal pieces
+    assert rdist.piece_tiles(8800, 8, 4) == [76, 512, 512]                     # nothing left for a fourth piece
+    assert rdist.piece_tiles(8 * 1025, 8, 4) == [513, 512]                     # a piece of one tile joins its neighbour
+    for n_tiles, world, pieces in ((36765, 8, 4), (8800, 8, 4), (12345, 4, 3), (5000, 8, 2)):
+        pt = rdist.piece_tiles(n_tiles, world, pieces)
+        assert sum(pt) * world >= n_tiles and len(pt) <= pieces and min(pt) > 0
 
 
 def test_two_ranks_balanced_cut_pinned_on_a_uniform_graph():
