@@ -348,6 +348,9 @@ def main():
 
     import __graft_entry__ as ge
     ge.build()          # before anything touches the GPU or the process group (hipcc is a child process)
+    if os.environ.get("RGCN_BENCH_WATCHDOG"):      # seconds: every rank dumps its Python stack to stderr that often (a hung multi-rank run says where)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RGCN_BENCH_WATCHDOG"]), repeat=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -16,6 +16,7 @@ ones, so P-rank outputs and dX are bit-identical to 1-rank ones; only d_weight s
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -35,7 +36,9 @@ def piece_rows(n_nodes: int, tile: int, world: int, pieces: int) -> int:
     return ((n_tiles + world * pieces - 1) // (world * pieces)) * tile
 
 
-CU_ROUND = 256   # workgroups one launch round of a tile kernel holds on an MI355X (one workgroup per CU: their LDS)
+# workgroups one launch round of a tile kernel holds on an MI355X (one workgroup per CU: their LDS); RGCN_CU_ROUND: rehearsals of
+# the pieces-of-whole-rounds cut on graphs too small for it
+CU_ROUND = int(os.environ.get("RGCN_CU_ROUND", 256))
 
 
 def piece_tiles(n_tiles: int, world: int, pieces: int):
@@ -141,9 +144,11 @@ def make_context(n_nodes: int, tile: int, group=None, pieces: int = PIECES, edge
             # rows of heavy segments are dealt over all ranks (eplan.SharedHeavy) wherever a direction takes the edge-parallel
             # path (``paths``: what the layer will run per direction; a direction on the tile kernels walks its hubs in their
             # block): they are not a block's cost.  What stays in a block: its light rows and one pseudo row per heavy segment.
-            hf, hb = heavy_edge_masks(edge_index, edge_type, n_nodes)
-            hf = hf if paths[0] == "ep" else None
-            hb = hb if paths[1] == "ep" else None
+            hf = hb = None
+            if "ep" in (paths[0], paths[1]):       # (a sort of the edge list: only where a direction will use it)
+                hf, hb = heavy_edge_masks(edge_index, edge_type, n_nodes)
+                hf = hf if paths[0] == "ep" else None
+                hb = hb if paths[1] == "ep" else None
             if hf is not None or hb is not None:
                 zero = torch.zeros(edge_index.shape[1], dtype=torch.bool, device=edge_index.device)
                 hf = zero if hf is None else hf
