@@ -164,3 +164,27 @@ def test_heavy_segments_are_aggregated_before_the_transform(golden, threshold):
             cur = np.stack([rows[ptr[i]:ptr[i + 1]].sum(0) for i in range(n_out)])
         dw = dw + emulate_dw(ep.heavy_tile_plan(), cur, golden["dout"], w_all.shape[0], w_all.shape[1], w_all.shape[2])
     np.testing.assert_allclose(dw[:-1], golden["d_wfull"], rtol=1e-6, atol=1e-6)
+
+
+def test_heavy_mask_equals_the_plain_sort_of_all_segment_keys():
+    """eplan.heavy_mask decides by node degree first and sorts only the keys of edges at nodes that could hold a heavy segment:
+    same mask as counting every (relation, node) key (what it did before: two torch.unique over 100M keys per rank at the
+    headline size), on a uniform graph, a hub graph, a threshold nothing reaches, and with a caller's "not mine" ids (-1)."""
+    from scaling_rgcn_training_amd.eplan import heavy_mask
+    g = torch.Generator().manual_seed(5)
+    n, e, r = 3000, 120000, 7
+    for hubs, negatives, thr in ((False, False, 16), (True, False, 16), (True, True, 16), (False, False, 10_000), (True, False, 64)):
+        sc = torch.randint(0, n, (e,), generator=g)
+        if hubs:
+            sc[: e // 3] = torch.randint(0, 5, (e // 3,), generator=g)
+        if negatives:
+            sc[::7] = -1
+        rel = torch.randint(0, r, (e,), generator=g)
+        _, inv, cnt = torch.unique(rel * (n + 1) + sc, return_inverse=True, return_counts=True)
+        want = (cnt[inv] >= thr) & (sc >= 0)
+        got = heavy_mask(sc, rel, n + 1, thr)
+        if got is None:
+            assert not bool(want.any())
+        else:
+            assert torch.equal(got, want)
+    assert heavy_mask(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 10, 16) is None
